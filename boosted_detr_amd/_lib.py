@@ -1,0 +1,126 @@
+"""ctypes binding of libbdetr.so (the C ABI declared in include/bdetr.h).
+
+The product path has NO fallback: if the HIP library is missing or a symbol cannot be
+resolved, importing this module's ``lib()`` raises.  Nothing here imports ``oracle``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+_LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libbdetr.so"
+_lib = None
+
+c_f32p = C.c_void_p     # device pointers are passed as integers (tensor.data_ptr())
+c_i32p = C.c_void_p
+c_i64p = C.c_void_p
+c_stream = C.c_void_p
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("N", "H", "W", "C", "K", "R", "S", "stride", "pad", "OH", "OW")]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("I", C.c_int), ("J", C.c_int), ("R", C.c_int), ("nb0", C.c_int), ("nb1", C.c_int),
+        ("a", C.c_void_p), ("lda", C.c_int64), ("sa0", C.c_int64), ("sa1", C.c_int64), ("a_rcontig", C.c_int),
+        ("b", C.c_void_p), ("ldb", C.c_int64), ("sb0", C.c_int64), ("sb1", C.c_int64), ("b_rcontig", C.c_int),
+        ("c", C.c_void_p), ("ldc", C.c_int64), ("sc0", C.c_int64), ("sc1", C.c_int64),
+        ("bias", C.c_void_p), ("alpha", C.c_float), ("act", C.c_int), ("accumulate", C.c_int), ("splitk", C.c_int),
+    ]
+
+
+class LossDesc(C.Structure):
+    _fields_ = [("B", C.c_int), ("M", C.c_int), ("N", C.c_int), ("C", C.c_int), ("A", C.c_int),
+                ("category_weight", C.c_float), ("attribute_weight", C.c_float),
+                ("box_weight", C.c_float), ("exist_weight", C.c_float)]
+
+
+P = C.c_void_p
+I = C.c_int
+L = C.c_int64
+F = C.c_float
+U64 = C.c_uint64
+
+# name -> (restype, argtypes); every symbol include/bdetr.h declares
+SIGNATURES = {
+    "bdetr_abi_version": (I, []),
+    "bdetr_last_error": (C.c_char_p, []),
+    "bdetr_device_cus": (I, []),
+    "bdetr_image_prep": (I, [P, I, I, I, P, I, I, P]),
+    "bdetr_conv2d_fwd": (I, [P, P, P, P, C.POINTER(ConvDesc), I, P, P, P]),
+    "bdetr_conv2d_fwd_stat_chunks": (I, [C.POINTER(ConvDesc)]),
+    "bdetr_conv2d_bwd_data": (I, [P, P, P, C.POINTER(ConvDesc), I, P]),
+    "bdetr_conv2d_bwd_weight": (I, [P, P, P, C.POINTER(ConvDesc), I, P]),
+    "bdetr_conv2d_bwd_weight_splitk": (I, [C.POINTER(ConvDesc)]),
+    "bdetr_gemm": (I, [C.POINTER(GemmDesc), P]),
+    "bdetr_colsum_chunks": (I, [L]),
+    "bdetr_colsum": (I, [P, L, I, P, P, P]),
+    "bdetr_colstats": (I, [P, L, I, P, P, P]),
+    "bdetr_bn_stats": (I, [P, L, I, P, P, I, F, F, I, P, P, P, P, P]),
+    "bdetr_bn_stats_frozen": (I, [P, P, I, F, P, P, P]),
+    "bdetr_bn_apply": (I, [P, P, P, P, P, P, I, P, L, I, P]),
+    "bdetr_bn_bwd_chunks": (I, [L]),
+    "bdetr_bn_bwd": (I, [P, P, P, P, P, P, I, I, P, P, P, P, P, L, I, P]),
+    "bdetr_maxpool3x3s2_fwd": (I, [P, P, I, I, I, I, I, I, P]),
+    "bdetr_maxpool3x3s2_bwd": (I, [P, P, P, P, I, I, I, I, I, I, P]),
+    "bdetr_softmax_rows_fwd": (I, [P, P, L, I, F, P]),
+    "bdetr_softmax_rows_bwd": (I, [P, P, P, L, I, F, P]),
+    "bdetr_add_dropout_layernorm_fwd": (I, [P, P, P, P, P, P, P, L, I, F, F, U64, P]),
+    "bdetr_ln_bwd_chunks": (I, [L]),
+    "bdetr_add_dropout_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, L, I, F, U64, I, P]),
+    "bdetr_softmax_lastdim_fwd": (I, [P, P, L, I, P]),
+    "bdetr_softmax_lastdim_bwd": (I, [P, P, P, L, I, P]),
+    "bdetr_sigmoid_fwd": (I, [P, P, L, P]),
+    "bdetr_sigmoid_bwd": (I, [P, P, P, L, P]),
+    "bdetr_boxsigmoid_fwd": (I, [P, P, L, P]),
+    "bdetr_boxsigmoid_bwd": (I, [P, P, P, L, P]),
+    "bdetr_zero": (I, [P, L, P]),
+    "bdetr_add": (I, [P, P, P, L, P]),
+    "bdetr_add_bcast_rows": (I, [P, P, P, L, L, P]),
+    "bdetr_sum_over_batch": (I, [P, P, L, L, I, P]),
+    "bdetr_tanh_bwd": (I, [P, P, P, L, P]),
+    "bdetr_relu_bwd": (I, [P, P, P, L, P]),
+    "bdetr_axpy": (I, [F, P, P, L, P]),
+    "bdetr_cost_matrix": (I, [C.POINTER(LossDesc), P, P, P, P, P, P, P, P, P, P, P, P]),
+    "bdetr_lsa": (I, [P, P, I, I, I, P, P]),
+    "bdetr_set_loss": (I, [C.POINTER(LossDesc), P, P, P, P, P, P, P, P, P, P, P, P, F, P]),
+    "bdetr_match_to_mask": (I, [P, P, I, I, I, P]),
+    "bdetr_sgd_slab_elems": (I, []),
+    "bdetr_sgd_nesterov_clipnorm": (I, [P, P, I, P, P, I, P, P, P, F, F, F, P]),
+}
+
+
+class BdetrError(RuntimeError):
+    pass
+
+
+def lib_path() -> Path:
+    return _LIB_PATH
+
+
+def lib():
+    """Load libbdetr.so (once) and bind every symbol.  Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not _LIB_PATH.exists():
+        raise BdetrError(
+            f"{_LIB_PATH} not found: the HIP extension is not built. Run `python -m boosted_detr_amd.build` "
+            "(or __graft_entry__.build()). There is no CPU fallback in the product path.")
+    h = C.CDLL(str(_LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(h, name)          # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if h.bdetr_abi_version() != 1:
+        raise BdetrError("libbdetr.so ABI version mismatch; rebuild")
+    _lib = h
+    return _lib
+
+
+def check(status: int, what: str = "") -> None:
+    if status != 0:
+        msg = lib().bdetr_last_error().decode(errors="replace")
+        raise BdetrError(f"{what or 'libbdetr'} failed (status {status}): {msg}")

@@ -1,0 +1,227 @@
+// elementwise.hip - HBM-bound pointwise / pooling kernels for gfx950 (fp32, grid-stride,
+// 16-byte accesses where the layout allows).
+//
+// Replaces: backbone.py:49-56 (image preparation), ResNet-50 pool1 (max-pool 3x3/2),
+// prediction_heads.py:44,180 (sigmoid variants), transformers.py Add layers, Keras
+// autodiff of tanh/relu.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float prep_px(float v) {        // clip happened before the resize
+    float q = floorf(v * 255.5f);                           // tf.image.convert_image_dtype(float->uint8): saturate_cast(x*255.5)
+    return fminf(fmaxf(q, 0.f), 255.f);
+}
+
+__global__ __launch_bounds__(256) void image_prep_kernel(const float* __restrict__ in, int B, int h, int w,
+                                                         float* __restrict__ out, int H, int W) {
+    const int64_t npix = (int64_t)B * H * W;
+    const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % W); const int64_t t = i / W; const int oy = (int)(t % H); const int b = (int)(t / H);
+        float rgb[3];
+        if (h == H && w == W) {
+            const float* p = in + i * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) rgb[c] = fminf(fmaxf(p[c], 0.f), 1.f);
+        } else {
+            // tf.keras.layers.Resizing: bilinear, half-pixel centres, no antialias
+            const float fy = ((float)oy + 0.5f) * sy - 0.5f, fx = ((float)ox + 0.5f) * sx - 0.5f;
+            const float fy0 = floorf(fy), fx0 = floorf(fx);
+            const int y0 = max((int)fy0, 0), y1 = min((int)ceilf(fy), h - 1);
+            const int x0 = max((int)fx0, 0), x1 = min((int)ceilf(fx), w - 1);
+            const float ly = fy - fy0, lx = fx - fx0;
+            const float* base = in + (int64_t)b * h * w * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                auto px = [&](int yy, int xx) { return fminf(fmaxf(base[((int64_t)yy * w + xx) * 3 + c], 0.f), 1.f); };
+                const float top = px(y0, x0) + (px(y0, x1) - px(y0, x0)) * lx;
+                const float bot = px(y1, x0) + (px(y1, x1) - px(y1, x0)) * lx;
+                rgb[c] = top + (bot - top) * ly;
+            }
+        }
+        // caffe-mode preprocess_input: RGB->BGR, subtract ImageNet mean
+        f32x4 o;
+        o[0] = prep_px(rgb[2]) - 103.939f;
+        o[1] = prep_px(rgb[1]) - 116.779f;
+        o[2] = prep_px(rgb[0]) - 123.68f;
+        o[3] = 0.f;
+        reinterpret_cast<f32x4*>(out)[i] = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          int N, int H, int W, int C, int OH, int OW) {
+    const int c4n = C / 4;
+    const int64_t n4 = (int64_t)N * OH * OW * c4n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n); int64_t t = i / c4n;
+        const int ow = (int)(t % OW); t /= OW; const int oh = (int)(t % OH); const int n = (int)(t / OH);
+        // zero padding (ZeroPadding2D) == -inf padding here because the input is post-ReLU; keep the literal zero-pad semantics
+        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int ih = oh * 2 - 1 + r, iw = ow * 2 - 1 + s;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+                    v = reinterpret_cast<const f32x4*>(x)[(((int64_t)n * H + ih) * W + iw) * c4n + c4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]);
+            }
+        reinterpret_cast<f32x4*>(y)[i] = m;
+    }
+}
+
+// gather form (no atomics): an input pixel receives dy of every window whose max it equals.
+// Ties only occur at post-ReLU zeros, whose gradient is masked by the producer's ReLU anyway.
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ dy,
+                                                          float* __restrict__ dx, int N, int H, int W, int C, int OH, int OW) {
+    const int c4n = C / 4;
+    const int64_t n4 = (int64_t)N * H * W * c4n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n); int64_t t = i / c4n;
+        const int iw = (int)(t % W); t /= W; const int ih = (int)(t % H); const int n = (int)(t / H);
+        const f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        // windows oh with oh*2-1 <= ih <= oh*2+1
+        const int oh_lo = max((ih) / 2, 0), oh_hi = min((ih + 1) / 2, OH - 1);
+        const int ow_lo = max((iw) / 2, 0), ow_hi = min((iw + 1) / 2, OW - 1);
+        for (int oh = oh_lo; oh <= oh_hi; ++oh)
+            for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+                const int64_t o = (((int64_t)n * OH + oh) * OW + ow) * c4n + c4;
+                const f32x4 yv = reinterpret_cast<const f32x4*>(y)[o];
+                const f32x4 dv = reinterpret_cast<const f32x4*>(dy)[o];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (xv[e] == yv[e]) g[e] += dv[e];
+            }
+        reinterpret_cast<f32x4*>(dx)[i] = g;
+    }
+}
+
+enum { EW_ZERO, EW_ADD, EW_SIGMOID, EW_SIGMOID_BWD, EW_BOXSIG, EW_BOXSIG_BWD, EW_TANH_BWD, EW_RELU_BWD, EW_AXPY };
+
+template <int OP>
+__global__ __launch_bounds__(256) void ew_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, int64_t n, float alpha) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float r;
+        if (OP == EW_ZERO) r = 0.f;
+        else if (OP == EW_ADD) r = a[i] + b[i];
+        else if (OP == EW_SIGMOID) r = 1.0f / (1.0f + expf(-a[i]));
+        else if (OP == EW_SIGMOID_BWD) { float y = a[i]; r = b[i] * y * (1.0f - y); }
+        else if (OP == EW_BOXSIG) r = 3.0f * (1.0f / (1.0f + expf(-(a[i] / 100.0f)))) - 1.0f;
+        else if (OP == EW_BOXSIG_BWD) { float s = (a[i] + 1.0f) / 3.0f; r = b[i] * 3.0f * s * (1.0f - s) / 100.0f; }
+        else if (OP == EW_TANH_BWD) { float y = a[i]; r = b[i] * (1.0f - y * y); }
+        else if (OP == EW_RELU_BWD) r = a[i] > 0.f ? b[i] : 0.f;
+        else r = o[i] + alpha * a[i];
+        o[i] = r;
+    }
+}
+
+__global__ __launch_bounds__(256) void add_bcast_rows_kernel(const float* __restrict__ a, const float* __restrict__ row, float* __restrict__ out,
+                                                             int64_t n, int64_t rowlen) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = a[i] + row[i % rowlen];
+}
+
+__global__ __launch_bounds__(256) void sum_over_batch_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t batch, int64_t n, int accumulate) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float s = accumulate ? out[i] : 0.f;
+        for (int64_t b = 0; b < batch; ++b) s += x[b * n + i];
+        out[i] = s;
+    }
+}
+
+// column sums of [rows][cols] (any cols), two deterministic levels: per-chunk partials, then a
+// fixed-order fp64 sum of the partials.  block = 64 columns x 4 row phases.
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int64_t rows, int cols, int64_t rows_per_chunk,
+                                                             float* __restrict__ part) {
+    __shared__ float s[256];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+    float a = 0.f;
+    if (c < cols) for (int64_t r = r0 + ry; r < r1; r += 4) a += x[r * cols + c];
+    s[threadIdx.x] = a;
+    __syncthreads();
+    if (ry == 0 && c < cols) part[(int64_t)blockIdx.y * cols + c] = s[cx] + s[cx + 64] + s[cx + 128] + s[cx + 192];
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int nparts, int cols, float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    double a = 0;
+    for (int p = 0; p < nparts; ++p) a += part[(int64_t)p * cols + c];
+    out[c] = (float)a;
+}
+
+template <int OP>
+int ew_launch(const char* who, const float* a, const float* b, float* o, int64_t n, float alpha, void* stream) {
+    BDETR_CHECK_ARG(o != nullptr && n >= 0, "%s: bad arguments", who);
+    if (n == 0) return 0;
+    hipLaunchKernelGGL((ew_kernel<OP>), dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, a, b, o, n, alpha);
+    return bdetr_launch_status(who);
+}
+
+}  // namespace
+
+extern "C" int bdetr_image_prep(const float* in, int B, int h, int w, float* out, int H, int W, void* stream) {
+    BDETR_CHECK_ARG(in && out && B > 0 && h > 0 && w > 0 && H > 0 && W > 0, "bdetr_image_prep: bad arguments");
+    int64_t n = (int64_t)B * H * W;
+    hipLaunchKernelGGL(image_prep_kernel, dim3(ew_grid(n, 256, 1)), dim3(256), 0, (hipStream_t)stream, in, B, h, w, out, H, W);
+    return bdetr_launch_status("image_prep");
+}
+
+extern "C" int bdetr_maxpool3x3s2_fwd(const float* x, float* y, int N, int H, int W, int C, int OH, int OW, void* stream) {
+    BDETR_CHECK_ARG(x && y && C % 4 == 0 && OH == (H + 2 - 3) / 2 + 1 && OW == (W + 2 - 3) / 2 + 1, "bdetr_maxpool3x3s2_fwd: bad arguments");
+    int64_t n4 = (int64_t)N * OH * OW * (C / 4);
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid(n4, 256, 1)), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W, C, OH, OW);
+    return bdetr_launch_status("maxpool_fwd");
+}
+extern "C" int bdetr_maxpool3x3s2_bwd(const float* x, const float* y, const float* dy, float* dx,
+                                      int N, int H, int W, int C, int OH, int OW, void* stream) {
+    BDETR_CHECK_ARG(x && y && dy && dx && C % 4 == 0 && OH == (H + 2 - 3) / 2 + 1 && OW == (W + 2 - 3) / 2 + 1, "bdetr_maxpool3x3s2_bwd: bad arguments");
+    int64_t n4 = (int64_t)N * H * W * (C / 4);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_grid(n4, 256, 1)), dim3(256), 0, (hipStream_t)stream, x, y, dy, dx, N, H, W, C, OH, OW);
+    return bdetr_launch_status("maxpool_bwd");
+}
+
+extern "C" int bdetr_zero(float* p, int64_t n, void* stream) {
+    BDETR_CHECK_ARG(p != nullptr && n >= 0, "bdetr_zero: bad arguments");
+    if (n == 0) return 0;
+    hipError_t e = hipMemsetAsync(p, 0, sizeof(float) * (size_t)n, (hipStream_t)stream);
+    if (e != hipSuccess) { bdetr_set_error("bdetr_zero: %s", hipGetErrorString(e)); return (int)e; }
+    return 0;
+}
+extern "C" int bdetr_add(const float* a, const float* b, float* out, int64_t n, void* stream) { return ew_launch<EW_ADD>("bdetr_add", a, b, out, n, 0.f, stream); }
+extern "C" int bdetr_sigmoid_fwd(const float* x, float* y, int64_t n, void* stream) { return ew_launch<EW_SIGMOID>("bdetr_sigmoid_fwd", x, nullptr, y, n, 0.f, stream); }
+extern "C" int bdetr_sigmoid_bwd(const float* y, const float* dy, float* dx, int64_t n, void* stream) { return ew_launch<EW_SIGMOID_BWD>("bdetr_sigmoid_bwd", y, dy, dx, n, 0.f, stream); }
+extern "C" int bdetr_boxsigmoid_fwd(const float* x, float* y, int64_t n, void* stream) { return ew_launch<EW_BOXSIG>("bdetr_boxsigmoid_fwd", x, nullptr, y, n, 0.f, stream); }
+extern "C" int bdetr_boxsigmoid_bwd(const float* y, const float* dy, float* dx, int64_t n, void* stream) { return ew_launch<EW_BOXSIG_BWD>("bdetr_boxsigmoid_bwd", y, dy, dx, n, 0.f, stream); }
+extern "C" int bdetr_tanh_bwd(const float* y, const float* dy, float* dx, int64_t n, void* stream) { return ew_launch<EW_TANH_BWD>("bdetr_tanh_bwd", y, dy, dx, n, 0.f, stream); }
+extern "C" int bdetr_relu_bwd(const float* y, const float* dy, float* dx, int64_t n, void* stream) { return ew_launch<EW_RELU_BWD>("bdetr_relu_bwd", y, dy, dx, n, 0.f, stream); }
+extern "C" int bdetr_axpy(float alpha, const float* x, float* y, int64_t n, void* stream) { return ew_launch<EW_AXPY>("bdetr_axpy", x, nullptr, y, n, alpha, stream); }
+
+extern "C" int bdetr_add_bcast_rows(const float* a, const float* row, float* out, int64_t rows, int64_t rowlen, void* stream) {
+    BDETR_CHECK_ARG(a && row && out && rows > 0 && rowlen > 0, "bdetr_add_bcast_rows: bad arguments");
+    int64_t n = rows * rowlen;
+    hipLaunchKernelGGL(add_bcast_rows_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, a, row, out, n, rowlen);
+    return bdetr_launch_status("add_bcast_rows");
+}
+extern "C" int bdetr_sum_over_batch(const float* x, float* out, int64_t batch, int64_t n, int accumulate, void* stream) {
+    BDETR_CHECK_ARG(x && out && batch > 0 && n > 0, "bdetr_sum_over_batch: bad arguments");
+    hipLaunchKernelGGL(sum_over_batch_kernel, dim3(ew_grid(n, 256, 1)), dim3(256), 0, (hipStream_t)stream, x, out, batch, n, accumulate);
+    return bdetr_launch_status("sum_over_batch");
+}
+extern "C" int bdetr_colsum_chunks(int64_t rows) {
+    int64_t rpc = cdiv64(rows, 256); if (rpc < 64) rpc = 64;
+    return (int)cdiv64(rows, rpc);
+}
+extern "C" int bdetr_colsum(const float* x, int64_t rows, int cols, float* out, float* ws, void* stream) {
+    BDETR_CHECK_ARG(x && out && ws && rows > 0 && cols > 0, "bdetr_colsum: bad arguments");
+    int64_t rpc = cdiv64(rows, 256); if (rpc < 64) rpc = 64;
+    int nch = (int)cdiv64(rows, rpc);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 63) / 64, nch), dim3(256), 0, (hipStream_t)stream, x, rows, cols, rpc, ws);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, nch, cols, out);
+    return bdetr_launch_status("colsum");
+}

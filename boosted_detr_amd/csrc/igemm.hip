@@ -1,0 +1,540 @@
+// igemm.hip - fp32 MFMA implicit-GEMM family for gfx950 (MI355X).
+//
+// One kernel template computes   C[i][j] (+)= act(alpha * sum_r A(i,r) * B(j,r) + bias[j])
+// with v_mfma_f32_32x32x2_f32 (exact fp32, 64-lane wavefronts), where each operand is
+// produced by a *loader* over its natural row-major matrix:
+//   DenseLoader  - plain matrix with a leading dimension (Dense layers, 1x1 convs, attention)
+//   PatchLoader  - on-the-fly im2col rows of an NHWC tensor (conv fwd / bwd-data / bwd-weight)
+//   WFlipLoader  - OHWI conv weights read as [(tap',k)][c] with flipped taps (3x3 bwd-data)
+// and staged into LDS either "r-contiguous" ([x][BK+4], read back with ds_read_b128) or
+// "x-contiguous" ([BK][BX], read back with ds_read_b32), so that the HBM->LDS copy is always a
+// straight 16-byte-per-lane coalesced copy and no operand ever needs a transposed copy in HBM.
+//
+// Replaces: Keras Conv2D / Dense / tf.linalg.matmul and their autodiff
+// (backbone.py:37-38,76-78; transformers.py:41-48,62-65,86,97,101,174-177;
+//  prediction_heads.py:40-43,106-110,175-179).
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 32;       // r-depth of one LDS stage
+constexpr int RPAD = 4;      // row padding (floats) of r-contiguous LDS tiles: conflict-free ds_read_b128
+constexpr int NTHREADS = 256;
+
+// ----------------------------------------------------------------------------------------
+// operand descriptors + loaders
+// ----------------------------------------------------------------------------------------
+struct DenseOp { const float* p; int64_t ld, s0, s1; int rows, cols; };
+struct PatchOp { const float* p; int N, H, W, C, OH, OW, R, S, stride, pad; int rows, cols; };
+struct WFlipOp { const float* p; int K, C, R, S; int rows, cols; };
+
+template <int VEC>
+struct DenseLoader {
+    using Op = DenseOp;
+    struct Ctx { const float* rowp; bool ok; };
+    static __device__ __forceinline__ const float* batch_base(const Op& op, int b0, int b1) {
+        return op.p + (int64_t)b0 * op.s0 + (int64_t)b1 * op.s1;
+    }
+    static __device__ __forceinline__ Ctx row_ctx(const Op& op, const float* base, int row) {
+        Ctx c; c.ok = row < op.rows; c.rowp = base + (int64_t)row * op.ld; return c;
+    }
+    static __device__ __forceinline__ f32x4 load(const Op& op, const Ctx& c, int col) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (VEC == 4) {
+            if (c.ok && col < op.cols) v = *reinterpret_cast<const f32x4*>(c.rowp + col);
+        } else {
+            if (c.ok) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (col + e < op.cols) v[e] = c.rowp[col + e];
+            }
+        }
+        return v;
+    }
+};
+
+struct PatchLoader {
+    using Op = PatchOp;
+    struct Ctx { int64_t nbase; int ih0, iw0; bool ok; };
+    static __device__ __forceinline__ const float* batch_base(const Op& op, int, int) { return op.p; }
+    static __device__ __forceinline__ Ctx row_ctx(const Op& op, const float*, int row) {
+        Ctx c; c.ok = row < op.rows;
+        int ohw = op.OH * op.OW;
+        int n = row / ohw; int rem = row - n * ohw;
+        int oh = rem / op.OW; int ow = rem - oh * op.OW;
+        c.nbase = (int64_t)n * op.H * op.W;
+        c.ih0 = oh * op.stride - op.pad; c.iw0 = ow * op.stride - op.pad;
+        return c;
+    }
+    static __device__ __forceinline__ f32x4 load(const Op& op, const Ctx& c, int col) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (c.ok && col < op.cols) {
+            int tap = col / op.C; int ch = col - tap * op.C;
+            int r = tap / op.S; int s = tap - r * op.S;
+            int ih = c.ih0 + r, iw = c.iw0 + s;
+            if ((unsigned)ih < (unsigned)op.H && (unsigned)iw < (unsigned)op.W)
+                v = *reinterpret_cast<const f32x4*>(op.p + ((c.nbase + (int64_t)ih * op.W + iw) * op.C + ch));
+        }
+        return v;
+    }
+};
+
+struct WFlipLoader {
+    using Op = WFlipOp;
+    struct Ctx { const float* rowp; bool ok; };
+    static __device__ __forceinline__ const float* batch_base(const Op& op, int, int) { return op.p; }
+    static __device__ __forceinline__ Ctx row_ctx(const Op& op, const float*, int row) {
+        Ctx c; c.ok = row < op.rows;
+        int tap = row / op.K; int k = row - tap * op.K;
+        int r = tap / op.S; int s = tap - r * op.S;
+        c.rowp = op.p + (((int64_t)k * op.R + (op.R - 1 - r)) * op.S + (op.S - 1 - s)) * op.C;
+        return c;
+    }
+    static __device__ __forceinline__ f32x4 load(const Op& op, const Ctx& c, int col) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (c.ok && col < op.cols) v = *reinterpret_cast<const f32x4*>(c.rowp + col);
+        return v;
+    }
+};
+
+// ----------------------------------------------------------------------------------------
+// epilogue / problem description
+// ----------------------------------------------------------------------------------------
+enum { ST_STORE = 0, ST_ACCUM = 1, ST_ATOMIC = 2 };
+
+struct GemmParams {
+    int I, J, R;
+    int nb1;                 // batch index z = b0*nb1 + b1 (when splitk == 1)
+    int splitk, r_chunk;     // split of the r range over gridDim.z (r_chunk multiple of BK)
+    int tiles_i, tiles_j;
+    float* c; int64_t ldc, sc0, sc1;
+    const float* bias; float alpha; int act; int mode;
+    float* stat_sum; float* stat_sq;    // [tiles_i*WM][J] partial column sums (may be null)
+    int rowmap;                         // scatter C rows through a strided-pixel map (conv s>1 bwd-data)
+    int rm_OW, rm_OHOW, rm_H, rm_W, rm_stride;
+};
+
+template <int BX, bool RC>
+struct TileGeom {
+    static constexpr int LDS_FLOATS = RC ? BX * (BK + RPAD) : BK * BX;
+    static constexpr int NV = BX * BK / 4 / NTHREADS;           // float4 vectors per thread per stage
+    static constexpr int VPR = RC ? BK / 4 : BX / 4;            // vectors per natural row
+    static constexpr int LDS_LD = RC ? BK + RPAD : BX;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == BDETR_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == BDETR_ACT_TANH) return tanhf(v);
+    return v;
+}
+
+template <int BM, int BN, int WM, int WN, class LA, bool A_RC, class LB, bool B_RC>
+__global__ __launch_bounds__(NTHREADS, 2)
+void igemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
+{
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int WTM = BM / WM, WTN = BN / WN;     // wave tile
+    constexpr int TM = WTM / 32, TN = WTN / 32;     // 32x32 MFMA tiles per wave
+    static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 MFMA tile");
+    using GA = TileGeom<BM, A_RC>;
+    using GB = TileGeom<BN, B_RC>;
+    static_assert(GA::NV >= 1 && GB::NV >= 1, "tile too small for 256 threads");
+
+    __shared__ __attribute__((aligned(16))) float lds[2 * (GA::LDS_FLOATS + GB::LDS_FLOATS)];
+    constexpr int STAGE_FLOATS = GA::LDS_FLOATS + GB::LDS_FLOATS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    // XCD-aware tile order: blocks that are dispatched to the same XCD (blockIdx % 8) get
+    // consecutive logical tiles, and tile_j is the fast index, so one XCD's L2 sees the same
+    // A rows (the expensive im2col gather) from neighbouring workgroups.
+    const int nwg = g.tiles_i * g.tiles_j;
+    int wg;
+    {
+        const int bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_i = wg / g.tiles_j, tile_j = wg - tile_i * g.tiles_j;
+    const int i0 = tile_i * BM, j0 = tile_j * BN;
+
+    int b0 = 0, b1 = 0, r_begin = 0, r_end = g.R;
+    if (g.splitk > 1) {
+        r_begin = blockIdx.z * g.r_chunk;
+        r_end = min(g.R, r_begin + g.r_chunk);
+    } else {
+        b0 = blockIdx.z / g.nb1; b1 = blockIdx.z - b0 * g.nb1;
+    }
+    const float* baseA = LA::batch_base(opa, b0, b1);
+    const float* baseB = LB::batch_base(opb, b0, b1);
+
+    // per-thread staging geometry
+    typename LA::Ctx ctxA[GA::NV];
+    typename LB::Ctx ctxB[GB::NV];
+    int colA[GA::NV], colB[GB::NV], ldsoffA[GA::NV], ldsoffB[GB::NV], rowA[GA::NV], rowB[GB::NV];
+#pragma unroll
+    for (int p = 0; p < GA::NV; ++p) {
+        int v = tid + NTHREADS * p;
+        int rt = v / GA::VPR, c4 = v - rt * GA::VPR;
+        rowA[p] = rt; colA[p] = 4 * c4; ldsoffA[p] = rt * GA::LDS_LD + 4 * c4;
+        if (A_RC) ctxA[p] = LA::row_ctx(opa, baseA, i0 + rt);
+    }
+#pragma unroll
+    for (int p = 0; p < GB::NV; ++p) {
+        int v = tid + NTHREADS * p;
+        int rt = v / GB::VPR, c4 = v - rt * GB::VPR;
+        rowB[p] = rt; colB[p] = 4 * c4; ldsoffB[p] = rt * GB::LDS_LD + 4 * c4;
+        if (B_RC) ctxB[p] = LB::row_ctx(opb, baseB, j0 + rt);
+    }
+
+    f32x4 stA[GA::NV], stB[GB::NV];
+    auto load_stage = [&](int r0) {
+#pragma unroll
+        for (int p = 0; p < GA::NV; ++p) {
+            if (A_RC) {
+                int col = r0 + colA[p];
+                f32x4 v = LA::load(opa, ctxA[p], col);
+                if (col >= r_end) v = f32x4{0.f, 0.f, 0.f, 0.f};     // split-K tail (r_end multiple of 4 or == R)
+                stA[p] = v;
+            } else {
+                int row = r0 + rowA[p];
+                typename LA::Ctx c = LA::row_ctx(opa, baseA, row < r_end ? row : 0x7fffffff);
+                stA[p] = LA::load(opa, c, i0 + colA[p]);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < GB::NV; ++p) {
+            if (B_RC) {
+                int col = r0 + colB[p];
+                f32x4 v = LB::load(opb, ctxB[p], col);
+                if (col >= r_end) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                stB[p] = v;
+            } else {
+                int row = r0 + rowB[p];
+                typename LB::Ctx c = LB::row_ctx(opb, baseB, row < r_end ? row : 0x7fffffff);
+                stB[p] = LB::load(opb, c, j0 + colB[p]);
+            }
+        }
+    };
+    auto write_stage = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < GA::NV; ++p) *reinterpret_cast<f32x4*>(lds + buf * STAGE_FLOATS + ldsoffA[p]) = stA[p];
+#pragma unroll
+        for (int p = 0; p < GB::NV; ++p) *reinterpret_cast<f32x4*>(lds + buf * STAGE_FLOATS + GA::LDS_FLOATS + ldsoffB[p]) = stB[p];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+    const int nk = (r_end - r_begin + BK - 1) / BK;
+    if (nk > 0) {
+        load_stage(r_begin);
+        write_stage(0);
+    }
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_stage(r_begin + (kt + 1) * BK);     // global loads in flight under the MFMAs
+
+        const float* sA = lds + buf * STAGE_FLOATS;
+        const float* sB = sA + GA::LDS_FLOATS;
+#pragma unroll
+        for (int kb = 0; kb < BK / 8; ++kb) {
+            f32x4 fa[TM], fb[TN];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const int xb = wm * WTM + a * 32 + li;
+                if (A_RC) {
+                    fa[a] = *reinterpret_cast<const f32x4*>(sA + xb * GA::LDS_LD + kb * 8 + 4 * lh);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) fa[a][e] = sA[(kb * 8 + 4 * lh + e) * GA::LDS_LD + xb];
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const int xb = wn * WTN + b * 32 + li;
+                if (B_RC) {
+                    fb[b] = *reinterpret_cast<const f32x4*>(sB + xb * GB::LDS_LD + kb * 8 + 4 * lh);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) fb[b][e] = sB[(kb * 8 + 4 * lh + e) * GB::LDS_LD + xb];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][e], fb[b][e], acc[a][b], 0, 0, 0);
+        }
+        if (kt + 1 < nk) write_stage(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---------------- epilogue ----------------
+    float* cbase = g.c + (int64_t)b0 * g.sc0 + (int64_t)b1 * g.sc1;
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int j = j0 + wn * WTN + b * 32 + li;
+        const bool jok = j < g.J;
+        const float bias = (g.bias != nullptr && jok) ? g.bias[j] : 0.f;
+        float csum = 0.f, csq = 0.f;
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int i = i0 + wm * WTM + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (i < g.I && jok) {
+                    float v = apply_act(g.alpha * acc[a][b][e] + bias, g.act);
+                    int64_t orow = i;
+                    if (g.rowmap) {
+                        int n = i / g.rm_OHOW; int rem = i - n * g.rm_OHOW;
+                        int oh = rem / g.rm_OW; int ow = rem - oh * g.rm_OW;
+                        orow = ((int64_t)n * g.rm_H + (int64_t)oh * g.rm_stride) * g.rm_W + (int64_t)ow * g.rm_stride;
+                    }
+                    float* dst = cbase + orow * g.ldc + j;
+                    if (g.mode == ST_STORE) *dst = v;
+                    else if (g.mode == ST_ACCUM) *dst += v;
+                    else atomicAdd(dst, v);
+                    csum += v; csq += v * v;
+                }
+            }
+        }
+        if (g.stat_sum != nullptr) {
+            csum += __shfl_xor(csum, 32, 64);
+            csq += __shfl_xor(csq, 32, 64);
+            if (lh == 0 && jok) {
+                const int64_t chunk = (int64_t)tile_i * WM + wm;
+                g.stat_sum[chunk * g.J + j] = csum;
+                g.stat_sq[chunk * g.J + j] = csq;
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// host-side dispatch
+// ----------------------------------------------------------------------------------------
+struct TileChoice { int bm, bn; };
+
+int g_num_cus = 0;
+int num_cus() {
+    if (g_num_cus == 0) {
+        int dev = 0; hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) g_num_cus = p.multiProcessorCount;
+        if (g_num_cus <= 0) g_num_cus = 256;
+    }
+    return g_num_cus;
+}
+
+// Pick the biggest tile that still gives every CU ~2 workgroups; small-J problems get narrow tiles.
+TileChoice choose_tile(int I, int J, int zdim) {
+    const int64_t want = 2LL * num_cus();
+    auto tiles = [&](int bm, int bn) { return cdiv64(I, bm) * cdiv64(J, bn) * zdim; };
+    if (J <= 32) return {128, 32};
+    if (J <= 64) return tiles(128, 64) >= want ? TileChoice{128, 64} : TileChoice{64, 64};
+    if (tiles(128, 128) >= want) return {128, 128};
+    return {64, 64};
+}
+
+template <int BM, int BN, int WM, int WN, class LA, bool A_RC, class LB, bool B_RC>
+int launch_cfg(const typename LA::Op& a, const typename LB::Op& b, GemmParams g, int zdim, hipStream_t st) {
+    g.tiles_i = (int)cdiv64(g.I, BM);
+    g.tiles_j = (int)cdiv64(g.J, BN);
+    dim3 grid(g.tiles_i * g.tiles_j, 1, zdim);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, LA, A_RC, LB, B_RC>), grid, dim3(NTHREADS), 0, st, a, b, g);
+    return bdetr_launch_status("igemm");
+}
+
+template <class LA, bool A_RC, class LB, bool B_RC>
+int launch_any(const typename LA::Op& a, const typename LB::Op& b, GemmParams g, int zdim, hipStream_t st, bool small_only = false) {
+    TileChoice t = small_only ? TileChoice{64, 64} : choose_tile(g.I, g.J, zdim);
+    if (t.bm == 128 && t.bn == 128) return launch_cfg<128, 128, 2, 2, LA, A_RC, LB, B_RC>(a, b, g, zdim, st);
+    if (t.bm == 128 && t.bn == 64)  return launch_cfg<128, 64, 2, 2, LA, A_RC, LB, B_RC>(a, b, g, zdim, st);
+    if (t.bm == 128 && t.bn == 32)  return launch_cfg<128, 32, 4, 1, LA, A_RC, LB, B_RC>(a, b, g, zdim, st);
+    return launch_cfg<64, 64, 2, 2, LA, A_RC, LB, B_RC>(a, b, g, zdim, st);
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// number of partial-statistics rows the epilogue writes for an (I,J) problem: tiles_i * WM
+int stat_chunks(int I, int J) {
+    TileChoice t = choose_tile(I, J, 1);
+    const int wm = (t.bm == 128 && t.bn == 32) ? 4 : 2;
+    return (int)cdiv64(I, t.bm) * wm;
+}
+
+void init_params(GemmParams& g) {
+    g = GemmParams{};
+    g.nb1 = 1; g.splitk = 1; g.alpha = 1.f; g.mode = ST_STORE;
+}
+
+}  // namespace
+
+// ----------------------------------------------------------------------------------------
+// C ABI
+// ----------------------------------------------------------------------------------------
+extern "C" int bdetr_device_cus(void) { return num_cus(); }
+
+extern "C" int bdetr_gemm(const bdetr_gemm_desc* d, void* stream) {
+    BDETR_CHECK_ARG(d && d->a && d->b && d->c, "bdetr_gemm: null pointer");
+    BDETR_CHECK_ARG(d->I > 0 && d->J > 0 && d->R >= 0, "bdetr_gemm: bad shape I=%d J=%d R=%d", d->I, d->J, d->R);
+    const int nb0 = d->nb0 > 0 ? d->nb0 : 1, nb1 = d->nb1 > 0 ? d->nb1 : 1;
+    const int splitk = d->splitk > 1 ? d->splitk : 1;
+    BDETR_CHECK_ARG(splitk == 1 || (nb0 * nb1 == 1 && !d->bias && d->act == 0), "bdetr_gemm: splitk needs a single plain GEMM");
+    hipStream_t st = (hipStream_t)stream;
+
+    DenseOp a{d->a, d->lda, d->sa0, d->sa1, d->a_rcontig ? d->I : d->R, d->a_rcontig ? d->R : d->I};
+    DenseOp b{d->b, d->ldb, d->sb0, d->sb1, d->b_rcontig ? d->J : d->R, d->b_rcontig ? d->R : d->J};
+    GemmParams g; init_params(g);
+    g.I = d->I; g.J = d->J; g.R = d->R; g.nb1 = nb1;
+    g.c = d->c; g.ldc = d->ldc; g.sc0 = d->sc0; g.sc1 = d->sc1;
+    g.bias = d->bias; g.alpha = d->alpha; g.act = d->act;
+    g.mode = splitk > 1 ? ST_ATOMIC : (d->accumulate ? ST_ACCUM : ST_STORE);
+    int zdim = nb0 * nb1;
+    if (splitk > 1) {
+        g.splitk = splitk;
+        g.r_chunk = (int)(cdiv64(cdiv64(d->R, splitk), BK) * BK);
+        zdim = (int)cdiv64(d->R, g.r_chunk);
+        g.splitk = zdim > 1 ? zdim : 2;   // >1 keeps the split code path (r_begin/r_end)
+    }
+    auto vec_ok = [&](const DenseOp& o) {
+        return aligned16(o.p) && o.ld % 4 == 0 && o.s0 % 4 == 0 && o.s1 % 4 == 0 && o.cols % 4 == 0;
+    };
+    const bool v4 = vec_ok(a) && vec_ok(b);
+    const bool arc = d->a_rcontig != 0, brc = d->b_rcontig != 0;
+    if (v4) {
+        if (arc && brc)   return launch_any<DenseLoader<4>, true, DenseLoader<4>, true>(a, b, g, zdim, st);
+        if (arc && !brc)  return launch_any<DenseLoader<4>, true, DenseLoader<4>, false>(a, b, g, zdim, st);
+        if (!arc && !brc) return launch_any<DenseLoader<4>, false, DenseLoader<4>, false>(a, b, g, zdim, st);
+        return launch_any<DenseLoader<4>, false, DenseLoader<4>, true>(a, b, g, zdim, st, true);
+    }
+    // unaligned fallback (scalar HBM loads): only tiny problems take it (82-wide heads, T=49 attention)
+    if (arc && brc)   return launch_any<DenseLoader<1>, true, DenseLoader<1>, true>(a, b, g, zdim, st, true);
+    if (arc && !brc)  return launch_any<DenseLoader<1>, true, DenseLoader<1>, false>(a, b, g, zdim, st, true);
+    if (!arc && !brc) return launch_any<DenseLoader<1>, false, DenseLoader<1>, false>(a, b, g, zdim, st, true);
+    return launch_any<DenseLoader<1>, false, DenseLoader<1>, true>(a, b, g, zdim, st, true);
+}
+
+static int check_conv(const bdetr_conv_desc* d, const char* who) {
+    BDETR_CHECK_ARG(d != nullptr, "%s: null desc", who);
+    BDETR_CHECK_ARG(d->N > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->K > 0 && d->R > 0 && d->S > 0 && d->stride > 0 && d->pad >= 0,
+                    "%s: bad conv geometry", who);
+    BDETR_CHECK_ARG(d->C % 4 == 0, "%s: input channels must be a multiple of 4 (got %d)", who, d->C);
+    BDETR_CHECK_ARG(d->OH == (d->H + 2 * d->pad - d->R) / d->stride + 1 && d->OW == (d->W + 2 * d->pad - d->S) / d->stride + 1,
+                    "%s: OH/OW inconsistent with geometry", who);
+    BDETR_CHECK_ARG((int64_t)d->N * d->OH * d->OW < (1LL << 31) && (int64_t)d->R * d->S * d->C < (1LL << 31), "%s: problem too large", who);
+    return 0;
+}
+
+extern "C" int bdetr_conv2d_fwd_stat_chunks(const bdetr_conv_desc* d) {
+    if (check_conv(d, "bdetr_conv2d_fwd_stat_chunks")) return -1;
+    return stat_chunks(d->N * d->OH * d->OW, d->K);
+}
+
+extern "C" int bdetr_conv2d_fwd(const float* x, const float* w, const float* bias, float* y,
+                                const bdetr_conv_desc* d, int act, float* stat_sum, float* stat_sq, void* stream) {
+    if (int e = check_conv(d, "bdetr_conv2d_fwd")) return e;
+    BDETR_CHECK_ARG(x && w && y, "bdetr_conv2d_fwd: null pointer");
+    BDETR_CHECK_ARG(aligned16(x) && aligned16(w), "bdetr_conv2d_fwd: x and w must be 16-byte aligned");
+    BDETR_CHECK_ARG((stat_sum == nullptr) == (stat_sq == nullptr), "bdetr_conv2d_fwd: stat_sum/stat_sq must both be set or both null");
+    const int M = d->N * d->OH * d->OW, Kd = d->R * d->S * d->C;
+    GemmParams g; init_params(g);
+    g.I = M; g.J = d->K; g.R = Kd;
+    g.c = y; g.ldc = d->K; g.bias = bias; g.act = act;
+    g.stat_sum = stat_sum; g.stat_sq = stat_sq;
+    DenseOp wop{w, Kd, 0, 0, d->K, Kd};
+    hipStream_t st = (hipStream_t)stream;
+    if (d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0) {
+        DenseOp xop{x, d->C, 0, 0, M, d->C};
+        return launch_any<DenseLoader<4>, true, DenseLoader<4>, true>(xop, wop, g, 1, st);
+    }
+    PatchOp xop{x, d->N, d->H, d->W, d->C, d->OH, d->OW, d->R, d->S, d->stride, d->pad, M, Kd};
+    return launch_any<PatchLoader, true, DenseLoader<4>, true>(xop, wop, g, 1, st);
+}
+
+extern "C" int bdetr_conv2d_bwd_data(const float* dy, const float* w, float* dx,
+                                     const bdetr_conv_desc* d, int accumulate, void* stream) {
+    if (int e = check_conv(d, "bdetr_conv2d_bwd_data")) return e;
+    BDETR_CHECK_ARG(dy && w && dx, "bdetr_conv2d_bwd_data: null pointer");
+    BDETR_CHECK_ARG(d->K % 4 == 0, "bdetr_conv2d_bwd_data: output channels must be a multiple of 4");
+    hipStream_t st = (hipStream_t)stream;
+    const int M = d->N * d->OH * d->OW;
+    GemmParams g; init_params(g);
+    g.c = dx; g.ldc = d->C; g.mode = accumulate ? ST_ACCUM : ST_STORE;
+    if (d->R == 1 && d->S == 1 && d->pad == 0) {
+        // dx[m][c] = sum_k dy[m][k] * w[k][c]; strided convs scatter their rows into the strided pixels
+        g.I = M; g.J = d->C; g.R = d->K;
+        if (d->stride > 1) {
+            if (!accumulate) {
+                hipError_t e = hipMemsetAsync(dx, 0, sizeof(float) * (size_t)d->N * d->H * d->W * d->C, st);
+                if (e != hipSuccess) { bdetr_set_error("bdetr_conv2d_bwd_data: memset: %s", hipGetErrorString(e)); return (int)e; }
+            }
+            g.rowmap = 1; g.rm_OW = d->OW; g.rm_OHOW = d->OH * d->OW; g.rm_H = d->H; g.rm_W = d->W; g.rm_stride = d->stride;
+        }
+        DenseOp a{dy, d->K, 0, 0, M, d->K};
+        DenseOp b{w, d->C, 0, 0, d->K, d->C};
+        return launch_any<DenseLoader<4>, true, DenseLoader<4>, false>(a, b, g, 1, st);
+    }
+    BDETR_CHECK_ARG(d->stride == 1, "bdetr_conv2d_bwd_data: stride>1 only for 1x1 convs");
+    // dx[n,ih,iw,c] = sum_{r,s,k} dy[n, ih+pad-r, iw+pad-s, k] * w[k][r][s][c]
+    //              = patch gather over dy with pad' = R-1-pad and flipped taps
+    const int Mx = d->N * d->H * d->W;
+    g.I = Mx; g.J = d->C; g.R = d->R * d->S * d->K;
+    PatchOp a{dy, d->N, d->OH, d->OW, d->K, d->H, d->W, d->R, d->S, 1, d->R - 1 - d->pad, Mx, d->R * d->S * d->K};
+    BDETR_CHECK_ARG(d->R == d->S, "bdetr_conv2d_bwd_data: square kernels only");
+    WFlipOp b{w, d->K, d->C, d->R, d->S, d->R * d->S * d->K, d->C};
+    return launch_any<PatchLoader, true, WFlipLoader, false>(a, b, g, 1, st);
+}
+
+extern "C" int bdetr_conv2d_bwd_weight_splitk(const bdetr_conv_desc* d) {
+    if (check_conv(d, "bdetr_conv2d_bwd_weight_splitk")) return -1;
+    const int M = d->N * d->OH * d->OW, Kd = d->R * d->S * d->C;
+    TileChoice t = choose_tile(d->K, Kd, 1);
+    int64_t tiles = cdiv64(d->K, t.bm) * cdiv64(Kd, t.bn);
+    int64_t want = 3LL * num_cus();
+    int64_t sk = cdiv64(want, tiles);
+    int64_t maxsk = cdiv64(M, 4 * BK);      // keep >= 4 stages per split
+    if (sk > maxsk) sk = maxsk;
+    if (sk < 1) sk = 1;
+    if (sk > 512) sk = 512;
+    return (int)sk;
+}
+
+extern "C" int bdetr_conv2d_bwd_weight(const float* x, const float* dy, float* dw,
+                                       const bdetr_conv_desc* d, int splitk, void* stream) {
+    if (int e = check_conv(d, "bdetr_conv2d_bwd_weight")) return e;
+    BDETR_CHECK_ARG(x && dy && dw, "bdetr_conv2d_bwd_weight: null pointer");
+    BDETR_CHECK_ARG(d->K % 4 == 0, "bdetr_conv2d_bwd_weight: output channels must be a multiple of 4");
+    hipStream_t st = (hipStream_t)stream;
+    const int M = d->N * d->OH * d->OW, Kd = d->R * d->S * d->C;
+    if (splitk <= 0) splitk = bdetr_conv2d_bwd_weight_splitk(d);
+    GemmParams g; init_params(g);
+    g.I = d->K; g.J = Kd; g.R = M;
+    g.c = dw; g.ldc = Kd;
+    int zdim = 1;
+    if (splitk > 1) {
+        g.r_chunk = (int)(cdiv64(cdiv64(M, splitk), BK) * BK);
+        zdim = (int)cdiv64(M, g.r_chunk);
+        g.splitk = zdim > 1 ? zdim : 2;
+        g.mode = ST_ATOMIC;
+    }
+    DenseOp a{dy, d->K, 0, 0, M, d->K};           // rows = r (pixels), cols = i (k)
+    if (d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0) {
+        DenseOp b{x, d->C, 0, 0, M, d->C};
+        return launch_any<DenseLoader<4>, false, DenseLoader<4>, false>(a, b, g, zdim, st);
+    }
+    PatchOp b{x, d->N, d->H, d->W, d->C, d->OH, d->OW, d->R, d->S, d->stride, d->pad, M, Kd};
+    return launch_any<DenseLoader<4>, false, PatchLoader, false>(a, b, g, zdim, st);
+}

@@ -1,0 +1,476 @@
+// norm.hip - HBM-bound normalisation kernels for gfx950: BatchNorm (training + frozen),
+// residual+dropout+LayerNorm, row softmax.  All fp32, 16-byte-per-lane coalesced accesses,
+// 64-lane wave reductions, deterministic two-level column reductions (no atomics).
+//
+// Replaces: keras BatchNormalization (backbone.py:79-80,92-94; ResNet-50 internals;
+// prediction_heads.py:42,108,177), keras LayerNormalization + Dropout + Add
+// (transformers.py:135-137,178-180), softmax (transformers.py:89, prediction_heads.py:111).
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------
+// column reductions over [rows][C] (C % 4 == 0): per-chunk partial sums of two quantities
+// ------------------------------------------------------------------------------------
+struct ColGeom { int tx, ty, gx; };
+inline ColGeom col_geom(int C) {
+    int c4 = C / 4;
+    int tx = 1; while (tx < c4 && tx < 64) tx <<= 1;     // threads along columns (power of two <= 64)
+    ColGeom g; g.tx = tx; g.ty = 256 / tx; g.gx = (c4 + tx - 1) / tx; return g;
+}
+
+// functor(row, c, &a4, &b4): the two float4 quantities to accumulate for columns c..c+3 of `row`
+template <class F>
+__global__ __launch_bounds__(256) void colreduce2_kernel(F f, int64_t rows, int C, int tx, int64_t rows_per_chunk,
+                                                         float* __restrict__ pa, float* __restrict__ pb) {
+    __shared__ f32x4 sa[256], sb[256];
+    const int tid = threadIdx.x;
+    const int cx = tid % tx, ry = tid / tx, ty = 256 / tx;
+    const int c = (blockIdx.x * tx + cx) * 4;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
+    const int64_t r1 = min(rows, r0 + rows_per_chunk);
+    f32x4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
+    if (c < C) {
+        for (int64_t r = r0 + ry; r < r1; r += ty) {
+            f32x4 qa, qb; f(r, c, qa, qb);
+            a += qa; b += qb;
+        }
+    }
+    sa[tid] = a; sb[tid] = b;
+    __syncthreads();
+    for (int s = ty >> 1; s > 0; s >>= 1) {
+        if (ry < s) { sa[tid] += sa[tid + s * tx]; sb[tid] += sb[tid + s * tx]; }
+        __syncthreads();
+    }
+    if (ry == 0 && c < C) {
+        *reinterpret_cast<f32x4*>(pa + (int64_t)blockIdx.y * C + c) = sa[tid];
+        *reinterpret_cast<f32x4*>(pb + (int64_t)blockIdx.y * C + c) = sb[tid];
+    }
+}
+
+// sum partials [nparts][C] in fp64, fixed order: 32 columns x 8 phases per block
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ psum, const float* __restrict__ psq, int nparts,
+                                                          int64_t rows, int C, float eps, float momentum, int bessel,
+                                                          float* mean, float* rstd, float* mmean, float* mvar) {
+    __shared__ double s1[256], s2[256];
+    const int cx = threadIdx.x & 31, py = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;
+    double a = 0, b = 0;
+    if (c < C) for (int p = py; p < nparts; p += 8) { a += psum[(int64_t)p * C + c]; b += psq[(int64_t)p * C + c]; }
+    s1[threadIdx.x] = a; s2[threadIdx.x] = b;
+    __syncthreads();
+    if (py == 0 && c < C) {
+        for (int k = 1; k < 8; ++k) { a += s1[cx + 32 * k]; b += s2[cx + 32 * k]; }
+        double m = a / (double)rows;
+        double var = b / (double)rows - m * m;
+        if (var < 0) var = 0;
+        mean[c] = (float)m;
+        rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (mmean != nullptr) {
+            double vm = (bessel && rows > 1) ? var * ((double)rows / (double)(rows - 1)) : var;
+            mmean[c] = mmean[c] * momentum + (float)m * (1.f - momentum);
+            mvar[c] = mvar[c] * momentum + (float)vm * (1.f - momentum);
+        }
+    }
+}
+
+__global__ void bn_frozen_kernel(const float* mm, const float* mv, int C, float eps, float* mean, float* rstd) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) { mean[c] = mm[c]; rstd[c] = 1.0f / sqrtf(mv[c] + eps); }
+}
+
+// sum partials [nparts][C] -> out1[C], out2[C] (fp32 inputs, fp64 accumulation, fixed order)
+__global__ __launch_bounds__(256) void sum_partials2_kernel(const float* __restrict__ pa, const float* __restrict__ pb, int nparts, int C,
+                                                            float* oa, float* ob) {
+    __shared__ double s1[256], s2[256];
+    const int cx = threadIdx.x & 31, py = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;
+    double a = 0, b = 0;
+    if (c < C) for (int p = py; p < nparts; p += 8) { a += pa[(int64_t)p * C + c]; b += pb[(int64_t)p * C + c]; }
+    s1[threadIdx.x] = a; s2[threadIdx.x] = b;
+    __syncthreads();
+    if (py == 0 && c < C) {
+        for (int k = 1; k < 8; ++k) { a += s1[cx + 32 * k]; b += s2[cx + 32 * k]; }
+        oa[c] = (float)a; ob[c] = (float)b;
+    }
+}
+
+struct StatFn {
+    const float* x; int C;
+    __device__ __forceinline__ void operator()(int64_t r, int c, f32x4& a, f32x4& b) const {
+        f32x4 v = *reinterpret_cast<const f32x4*>(x + r * C + c);
+        a = v; b = v * v;
+    }
+};
+
+struct BnBwdFn {   // a = g (masked dout), b = g * xhat
+    const float* dout; const float* out; const float* x; const float* mean; const float* rstd; int C; int relu;
+    __device__ __forceinline__ void operator()(int64_t r, int c, f32x4& a, f32x4& b) const {
+        f32x4 g = *reinterpret_cast<const f32x4*>(dout + r * C + c);
+        if (relu) {
+            f32x4 o = *reinterpret_cast<const f32x4*>(out + r * C + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (!(o[e] > 0.f)) g[e] = 0.f;
+        }
+        f32x4 xv = *reinterpret_cast<const f32x4*>(x + r * C + c);
+        f32x4 m = *reinterpret_cast<const f32x4*>(mean + c);
+        f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + c);
+        a = g; b = g * ((xv - m) * rs);
+    }
+};
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ residual, int relu, float* __restrict__ out,
+                                                       int64_t n4, int c4n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4n) * 4;
+        f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        f32x4 m = *reinterpret_cast<const f32x4*>(mean + c), rs = *reinterpret_cast<const f32x4*>(rstd + c);
+        f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c), b = *reinterpret_cast<const f32x4*>(beta + c);
+        f32x4 o = (v - m) * (rs * g) + b;
+        if (residual != nullptr) o += reinterpret_cast<const f32x4*>(residual)[i];
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+        }
+        reinterpret_cast<f32x4*>(out)[i] = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ out, const float* __restrict__ x,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ dgamma, const float* __restrict__ dbeta, int relu, int frozen,
+                                                           float* __restrict__ dx, float* __restrict__ dres, int64_t n4, int c4n, float inv_rows) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4n) * 4;
+        f32x4 g = reinterpret_cast<const f32x4*>(dout)[i];
+        if (relu) {
+            f32x4 o = reinterpret_cast<const f32x4*>(out)[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (!(o[e] > 0.f)) g[e] = 0.f;
+        }
+        if (dres != nullptr) reinterpret_cast<f32x4*>(dres)[i] = g;
+        f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + c), gm = *reinterpret_cast<const f32x4*>(gamma + c);
+        f32x4 r;
+        if (frozen) {
+            r = g * (rs * gm);
+        } else {
+            f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
+            f32x4 m = *reinterpret_cast<const f32x4*>(mean + c);
+            f32x4 dg = *reinterpret_cast<const f32x4*>(dgamma + c), db = *reinterpret_cast<const f32x4*>(dbeta + c);
+            f32x4 xh = (xv - m) * rs;
+            r = (g - db * inv_rows - xh * (dg * inv_rows)) * (rs * gm);
+        }
+        reinterpret_cast<f32x4*>(dx)[i] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, D % 4 == 0, D <= 64*4*LN_MAXV
+// ------------------------------------------------------------------------------------
+constexpr int LN_MAXV = 4;   // float4 per lane -> D <= 1024
+
+__device__ __forceinline__ uint32_t hash_u64(uint64_t z) {   // splitmix64 finaliser
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (uint32_t)(z >> 32);
+}
+__device__ __forceinline__ float keep_scale(uint64_t seed, uint64_t idx, uint32_t thresh, float inv_keep) {
+    return hash_u64(seed ^ (idx * 0xD6E8FEB86659FD93ull)) >= thresh ? inv_keep : 0.f;
+}
+
+__global__ __launch_bounds__(256) void add_drop_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              float* __restrict__ out, float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                                              int64_t rows, int D, float eps, float rate, uint64_t seed) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int d4 = D / 4;
+    const uint32_t thresh = rate > 0.f ? (uint32_t)fminf(rate * 4294967296.0f, 4294967295.0f) : 0u;
+    const float inv_keep = rate > 0.f ? 1.0f / (1.0f - rate) : 1.0f;
+    f32x4 h[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+        const int c4 = lane + 64 * k;
+        h[k] = f32x4{0, 0, 0, 0};
+        if (c4 < d4) {
+            f32x4 xv = reinterpret_cast<const f32x4*>(x + row * D)[c4];
+            f32x4 yv = reinterpret_cast<const f32x4*>(y + row * D)[c4];
+            if (rate > 0.f) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) yv[e] *= keep_scale(seed, (uint64_t)(row * D + c4 * 4 + e), thresh, inv_keep);
+            }
+            h[k] = xv + yv;
+            s += h[k][0] + h[k][1] + h[k][2] + h[k][3];
+        }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+        if (lane + 64 * k < d4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { float t = h[k][e] - mean; q += t * t; }
+        }
+    }
+    const float var = wave_sum(q) / (float)D;
+    const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+        const int c4 = lane + 64 * k;
+        if (c4 < d4) {
+            f32x4 g = reinterpret_cast<const f32x4*>(gamma)[c4], b = reinterpret_cast<const f32x4*>(beta)[c4];
+            reinterpret_cast<f32x4*>(out + row * D)[c4] = (h[k] - mean) * rstd * g + b;
+        }
+    }
+    if (lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
+}
+
+// one block = one chunk of rows; 4 waves, each row handled by one wave; column partials of
+// dgamma/dbeta kept in registers, combined through LDS at the end.
+__global__ __launch_bounds__(256) void add_drop_ln_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ x, const float* __restrict__ y,
+                                                              const float* __restrict__ gamma, const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
+                                                              float* __restrict__ dx, float* __restrict__ dy, float* __restrict__ pdg, float* __restrict__ pdb,
+                                                              int64_t rows, int D, int64_t rows_per_chunk, float rate, uint64_t seed, int accumulate_dx) {
+    __shared__ f32x4 sg[4][64 * LN_MAXV], sb[4][64 * LN_MAXV];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int d4 = D / 4;
+    const uint32_t thresh = rate > 0.f ? (uint32_t)fminf(rate * 4294967296.0f, 4294967295.0f) : 0u;
+    const float inv_keep = rate > 0.f ? 1.0f / (1.0f - rate) : 1.0f;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+    f32x4 adg[LN_MAXV], adb[LN_MAXV], gm[LN_MAXV];
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) {
+        adg[k] = f32x4{0, 0, 0, 0}; adb[k] = f32x4{0, 0, 0, 0}; gm[k] = f32x4{0, 0, 0, 0};
+        if (lane + 64 * k < d4) gm[k] = reinterpret_cast<const f32x4*>(gamma)[lane + 64 * k];
+    }
+    for (int64_t row = r0 + wave; row < r1; row += 4) {
+        const float mean = mean_i[row], rstd = rstd_i[row];
+        f32x4 xh[LN_MAXV], g[LN_MAXV], keep[LN_MAXV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < LN_MAXV; ++k) {
+            const int c4 = lane + 64 * k;
+            xh[k] = f32x4{0, 0, 0, 0}; g[k] = f32x4{0, 0, 0, 0}; keep[k] = f32x4{1, 1, 1, 1};
+            if (c4 < d4) {
+                f32x4 xv = reinterpret_cast<const f32x4*>(x + row * D)[c4];
+                f32x4 yv = reinterpret_cast<const f32x4*>(y + row * D)[c4];
+                if (rate > 0.f) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) keep[k][e] = keep_scale(seed, (uint64_t)(row * D + c4 * 4 + e), thresh, inv_keep);
+                    yv *= keep[k];
+                }
+                f32x4 dov = reinterpret_cast<const f32x4*>(dout + row * D)[c4];
+                xh[k] = (xv + yv - mean) * rstd;
+                g[k] = dov * gm[k];
+                adg[k] += dov * xh[k]; adb[k] += dov;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s1 += g[k][e]; s2 += g[k][e] * xh[k][e]; }
+            }
+        }
+        const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int k = 0; k < LN_MAXV; ++k) {
+            const int c4 = lane + 64 * k;
+            if (c4 < d4) {
+                f32x4 dh = (g[k] - m1 - xh[k] * m2) * rstd;
+                f32x4* dxp = reinterpret_cast<f32x4*>(dx + row * D) + c4;
+                if (accumulate_dx) *dxp += dh; else *dxp = dh;
+                reinterpret_cast<f32x4*>(dy + row * D)[c4] = dh * keep[k];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < LN_MAXV; ++k) { sg[wave][lane + 64 * k] = adg[k]; sb[wave][lane + 64 * k] = adb[k]; }
+    __syncthreads();
+    for (int c4 = threadIdx.x; c4 < d4; c4 += 256) {
+        f32x4 a = sg[0][c4] + sg[1][c4] + sg[2][c4] + sg[3][c4];
+        f32x4 b = sb[0][c4] + sb[1][c4] + sb[2][c4] + sb[3][c4];
+        reinterpret_cast<f32x4*>(pdg + (int64_t)blockIdx.x * D)[c4] = a;
+        reinterpret_cast<f32x4*>(pdb + (int64_t)blockIdx.x * D)[c4] = b;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// row softmax: one wave per row, up to 64*NPER columns held in registers
+// ------------------------------------------------------------------------------------
+template <int NPER>
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ s, float* __restrict__ p, int64_t rows, int cols, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float v[NPER];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < NPER; ++k) {
+        const int c = lane + 64 * k;
+        v[k] = c < cols ? s[row * cols + c] * scale : -INFINITY;
+        mx = fmaxf(mx, v[k]);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < NPER; ++k) { v[k] = lane + 64 * k < cols ? expf(v[k] - mx) : 0.f; sum += v[k]; }
+    sum = wave_sum(sum);
+#pragma unroll
+    for (int k = 0; k < NPER; ++k) { const int c = lane + 64 * k; if (c < cols) p[row * cols + c] = v[k] / sum; }
+}
+
+template <int NPER>
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ p, const float* __restrict__ dp, float* __restrict__ ds,
+                                                          int64_t rows, int cols, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float pv[NPER], dv[NPER];
+    float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < NPER; ++k) {
+        const int c = lane + 64 * k;
+        pv[k] = c < cols ? p[row * cols + c] : 0.f;
+        dv[k] = c < cols ? dp[row * cols + c] : 0.f;
+        dot += pv[k] * dv[k];
+    }
+    dot = wave_sum(dot);
+#pragma unroll
+    for (int k = 0; k < NPER; ++k) { const int c = lane + 64 * k; if (c < cols) ds[row * cols + c] = scale * pv[k] * (dv[k] - dot); }
+}
+
+int64_t chunk_rows_for(int64_t rows, int64_t maxchunks, int64_t minrows) {
+    int64_t rpc = cdiv64(rows, maxchunks);
+    if (rpc < minrows) rpc = minrows;
+    return rpc;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------
+extern "C" int bdetr_bn_bwd_chunks(int64_t rows) { return (int)cdiv64(rows, chunk_rows_for(rows, 512, 64)); }
+extern "C" int bdetr_ln_bwd_chunks(int64_t rows) { return (int)cdiv64(rows, chunk_rows_for(rows, 512, 16)); }
+
+extern "C" int bdetr_bn_stats(const float* x, int64_t rows, int C, const float* part_sum, const float* part_sq,
+                              int nparts, float eps, float momentum, int bessel,
+                              float* mean, float* rstd, float* moving_mean, float* moving_var, void* stream) {
+    BDETR_CHECK_ARG(mean && rstd && rows > 0 && C > 0, "bdetr_bn_stats: bad arguments");
+    BDETR_CHECK_ARG(part_sum != nullptr && part_sq != nullptr && nparts > 0,
+                    "bdetr_bn_stats: partial sums required (use bdetr_colstats to produce them from x)");
+    (void)x;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, part_sum, part_sq, nparts, rows, C, eps, momentum, bessel,
+                       mean, rstd, moving_mean, moving_var);
+    return bdetr_launch_status("bn_finalize");
+}
+
+// partial column sums of x and x*x: part_* are [bdetr_bn_bwd_chunks(rows)][C]
+extern "C" int bdetr_colstats(const float* x, int64_t rows, int C, float* part_sum, float* part_sq, void* stream) {
+    BDETR_CHECK_ARG(x && part_sum && part_sq && rows > 0 && C > 0 && C % 4 == 0, "bdetr_colstats: bad arguments (C %% 4 == 0 required)");
+    ColGeom g = col_geom(C);
+    int64_t rpc = chunk_rows_for(rows, 512, 64);
+    int nch = (int)cdiv64(rows, rpc);
+    StatFn f{x, C};
+    hipLaunchKernelGGL((colreduce2_kernel<StatFn>), dim3(g.gx, nch), dim3(256), 0, (hipStream_t)stream, f, rows, C, g.tx, rpc, part_sum, part_sq);
+    return bdetr_launch_status("colstats");
+}
+
+extern "C" int bdetr_bn_stats_frozen(const float* moving_mean, const float* moving_var, int C, float eps,
+                                     float* mean, float* rstd, void* stream) {
+    BDETR_CHECK_ARG(moving_mean && moving_var && mean && rstd && C > 0, "bdetr_bn_stats_frozen: bad arguments");
+    hipLaunchKernelGGL(bn_frozen_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, moving_mean, moving_var, C, eps, mean, rstd);
+    return bdetr_launch_status("bn_frozen");
+}
+
+extern "C" int bdetr_bn_apply(const float* x, const float* mean, const float* rstd, const float* gamma,
+                              const float* beta, const float* residual, int relu, float* out,
+                              int64_t rows, int C, void* stream) {
+    BDETR_CHECK_ARG(x && mean && rstd && gamma && beta && out && rows > 0 && C > 0 && C % 4 == 0, "bdetr_bn_apply: bad arguments (C %% 4 == 0 required)");
+    int64_t n4 = rows * C / 4;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(n4, 256, 2)), dim3(256), 0, (hipStream_t)stream, x, mean, rstd, gamma, beta, residual, relu, out, n4, C / 4);
+    return bdetr_launch_status("bn_apply");
+}
+
+extern "C" int bdetr_bn_bwd(const float* dout, const float* out, const float* x, const float* mean,
+                            const float* rstd, const float* gamma, int relu, int frozen,
+                            float* dx, float* dgamma, float* dbeta, float* dresidual,
+                            float* ws, int64_t rows, int C, void* stream) {
+    BDETR_CHECK_ARG(dout && x && mean && rstd && gamma && dx && dgamma && dbeta && ws && rows > 0 && C > 0 && C % 4 == 0,
+                    "bdetr_bn_bwd: bad arguments (C %% 4 == 0 required)");
+    BDETR_CHECK_ARG(!relu || out, "bdetr_bn_bwd: relu needs the forward output");
+    hipStream_t st = (hipStream_t)stream;
+    ColGeom g = col_geom(C);
+    int64_t rpc = chunk_rows_for(rows, 512, 64);
+    int nch = (int)cdiv64(rows, rpc);
+    float* pa = ws; float* pb = ws + (int64_t)nch * C;
+    BnBwdFn f{dout, out, x, mean, rstd, C, relu};
+    hipLaunchKernelGGL((colreduce2_kernel<BnBwdFn>), dim3(g.gx, nch), dim3(256), 0, st, f, rows, C, g.tx, rpc, pa, pb);
+    hipLaunchKernelGGL(sum_partials2_kernel, dim3((C + 31) / 32), dim3(256), 0, st, pa, pb, nch, C, dbeta, dgamma);
+    int64_t n4 = rows * C / 4;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n4, 256, 2)), dim3(256), 0, st, dout, out, x, mean, rstd, gamma, dgamma, dbeta,
+                       relu, frozen, dx, dresidual, n4, C / 4, 1.0f / (float)rows);
+    return bdetr_launch_status("bn_bwd");
+}
+
+extern "C" int bdetr_add_dropout_layernorm_fwd(const float* x, const float* y, const float* gamma, const float* beta,
+                                               float* out, float* mean, float* rstd, int64_t rows, int D,
+                                               float eps, float rate, uint64_t seed, void* stream) {
+    BDETR_CHECK_ARG(x && y && gamma && beta && out && mean && rstd && rows > 0, "bdetr_add_dropout_layernorm_fwd: null/empty argument");
+    BDETR_CHECK_ARG(D % 4 == 0 && D > 0 && D <= 256 * LN_MAXV, "bdetr_add_dropout_layernorm_fwd: D=%d unsupported (multiple of 4, <= %d)", D, 256 * LN_MAXV);
+    BDETR_CHECK_ARG(rate >= 0.f && rate < 1.f, "bdetr_add_dropout_layernorm_fwd: dropout rate must be in [0,1)");
+    hipLaunchKernelGGL(add_drop_ln_fwd_kernel, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, (hipStream_t)stream,
+                       x, y, gamma, beta, out, mean, rstd, rows, D, eps, rate, seed);
+    return bdetr_launch_status("add_dropout_layernorm_fwd");
+}
+
+extern "C" int bdetr_add_dropout_layernorm_bwd(const float* dout, const float* x, const float* y, const float* gamma,
+                                               const float* mean, const float* rstd, float* dx, float* dy,
+                                               float* dgamma, float* dbeta, float* ws, int64_t rows, int D,
+                                               float rate, uint64_t seed, int accumulate_dx, void* stream) {
+    BDETR_CHECK_ARG(dout && x && y && gamma && mean && rstd && dx && dy && dgamma && dbeta && ws && rows > 0,
+                    "bdetr_add_dropout_layernorm_bwd: null/empty argument");
+    BDETR_CHECK_ARG(D % 4 == 0 && D > 0 && D <= 256 * LN_MAXV, "bdetr_add_dropout_layernorm_bwd: D=%d unsupported", D);
+    hipStream_t st = (hipStream_t)stream;
+    int64_t rpc = chunk_rows_for(rows, 512, 16);
+    int nch = (int)cdiv64(rows, rpc);
+    float* pg = ws; float* pb = ws + (int64_t)nch * D;
+    hipLaunchKernelGGL(add_drop_ln_bwd_kernel, dim3(nch), dim3(256), 0, st, dout, x, y, gamma, mean, rstd, dx, dy, pg, pb,
+                       rows, D, rpc, rate, seed, accumulate_dx);
+    hipLaunchKernelGGL(sum_partials2_kernel, dim3((D + 31) / 32), dim3(256), 0, st, pg, pb, nch, D, dgamma, dbeta);
+    return bdetr_launch_status("add_dropout_layernorm_bwd");
+}
+
+static int softmax_dispatch(bool bwd, const float* a, const float* b, float* o, int64_t rows, int cols, float scale, hipStream_t st) {
+    dim3 grid((unsigned)cdiv64(rows, 4)), block(256);
+    const int nper = (cols + 63) / 64;
+#define SM_LAUNCH(N)                                                                                          \
+    do {                                                                                                      \
+        if (bwd) hipLaunchKernelGGL((softmax_bwd_kernel<N>), grid, block, 0, st, a, b, o, rows, cols, scale); \
+        else hipLaunchKernelGGL((softmax_fwd_kernel<N>), grid, block, 0, st, a, o, rows, cols, scale);        \
+    } while (0)
+    if (nper <= 2) SM_LAUNCH(2);
+    else if (nper <= 8) SM_LAUNCH(8);
+    else if (nper <= 32) SM_LAUNCH(32);
+    else { bdetr_set_error("softmax: cols=%d exceeds 2048", cols); return -1; }
+#undef SM_LAUNCH
+    return bdetr_launch_status("softmax");
+}
+
+extern "C" int bdetr_softmax_rows_fwd(const float* s, float* p, int64_t rows, int cols, float scale, void* stream) {
+    BDETR_CHECK_ARG(s && p && rows > 0 && cols > 0, "bdetr_softmax_rows_fwd: bad arguments");
+    return softmax_dispatch(false, s, nullptr, p, rows, cols, scale, (hipStream_t)stream);
+}
+extern "C" int bdetr_softmax_rows_bwd(const float* p, const float* dp, float* ds, int64_t rows, int cols, float scale, void* stream) {
+    BDETR_CHECK_ARG(p && dp && ds && rows > 0 && cols > 0, "bdetr_softmax_rows_bwd: bad arguments");
+    return softmax_dispatch(true, p, dp, ds, rows, cols, scale, (hipStream_t)stream);
+}
+extern "C" int bdetr_softmax_lastdim_fwd(const float* logits, float* p, int64_t rows, int cols, void* stream) {
+    return bdetr_softmax_rows_fwd(logits, p, rows, cols, 1.0f, stream);
+}
+extern "C" int bdetr_softmax_lastdim_bwd(const float* p, const float* dp, float* dlogits, int64_t rows, int cols, void* stream) {
+    return bdetr_softmax_rows_bwd(p, dp, dlogits, rows, cols, 1.0f, stream);
+}

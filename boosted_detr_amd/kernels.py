@@ -1,0 +1,400 @@
+"""Thin typed wrappers over the C ABI (include/bdetr.h).
+
+PyTorch-ROCm tensors are used ONLY as device-memory containers (``data_ptr()``) and for the
+current HIP stream; every arithmetic operation below is a hand-written HIP kernel in
+``csrc/``.  There is no eager/PyTorch fallback: a missing library raises in ``_lib.lib()``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, GemmDesc, LossDesc, check
+
+ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def _chk(*tensors, dtype=torch.float32):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.BdetrError("kernel operands must live in HBM (cuda tensors); no CPU path exists")
+        if t.dtype != dtype:
+            raise _lib.BdetrError(f"expected {dtype}, got {t.dtype}")
+        if not t.is_contiguous():
+            raise _lib.BdetrError("kernel operands must be contiguous")
+
+
+def empty(*shape, like: torch.Tensor, dtype=torch.float32) -> torch.Tensor:
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+# --------------------------------------------------------------------------------------
+# K1
+# --------------------------------------------------------------------------------------
+def image_prep(image: torch.Tensor, H: int, W: int) -> torch.Tensor:
+    """backbone.py:49-56.  image [B,h,w,3] in [0,1] -> [B,H,W,4] (BGR - mean, pad channel 0)."""
+    _chk(image)
+    B, h, w, c = image.shape
+    assert c == 3
+    out = empty(B, H, W, 4, like=image)
+    check(_lib.lib().bdetr_image_prep(_p(image), B, h, w, _p(out), H, W, _stream()), "image_prep")
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# convolution family
+# --------------------------------------------------------------------------------------
+@dataclass(frozen=True)
+class ConvGeom:
+    N: int
+    H: int
+    W: int
+    C: int
+    K: int
+    R: int
+    S: int
+    stride: int
+    pad: int
+
+    @property
+    def OH(self) -> int:
+        return (self.H + 2 * self.pad - self.R) // self.stride + 1
+
+    @property
+    def OW(self) -> int:
+        return (self.W + 2 * self.pad - self.S) // self.stride + 1
+
+    @property
+    def M(self) -> int:
+        return self.N * self.OH * self.OW
+
+    def desc(self) -> ConvDesc:
+        return ConvDesc(self.N, self.H, self.W, self.C, self.K, self.R, self.S, self.stride, self.pad, self.OH, self.OW)
+
+
+def conv2d_fwd(x, w, bias, g: ConvGeom, act: int = ACT_NONE, want_stats: bool = False):
+    """x [N,H,W,C], w [K,R,S,C] (OHWI), bias [K] -> y [N,OH,OW,K] (+ partial column stats)."""
+    _chk(x, w, bias)
+    L = _lib.lib()
+    d = g.desc()
+    y = empty(g.N, g.OH, g.OW, g.K, like=x)
+    psum = psq = None
+    nparts = 0
+    if want_stats:
+        nparts = L.bdetr_conv2d_fwd_stat_chunks(C.byref(d))
+        if nparts <= 0:
+            check(-1, "conv2d_fwd_stat_chunks")
+        psum = empty(nparts, g.K, like=x)
+        psq = empty(nparts, g.K, like=x)
+    check(L.bdetr_conv2d_fwd(_p(x), _p(w), _p(bias), _p(y), C.byref(d), act, _p(psum), _p(psq), _stream()), "conv2d_fwd")
+    return y, (psum, psq, nparts)
+
+
+def conv2d_bwd_data(dy, w, g: ConvGeom, dx: Optional[torch.Tensor] = None, accumulate: bool = False):
+    _chk(dy, w, dx)
+    d = g.desc()
+    if dx is None:
+        assert not accumulate
+        dx = empty(g.N, g.H, g.W, g.C, like=dy)
+    check(_lib.lib().bdetr_conv2d_bwd_data(_p(dy), _p(w), _p(dx), C.byref(d), int(accumulate), _stream()), "conv2d_bwd_data")
+    return dx
+
+
+def conv2d_bwd_weight(x, dy, g: ConvGeom, dw: Optional[torch.Tensor] = None):
+    _chk(x, dy, dw)
+    L = _lib.lib()
+    d = g.desc()
+    if dw is None:
+        dw = empty(g.K, g.R, g.S, g.C, like=x)
+    sk = L.bdetr_conv2d_bwd_weight_splitk(C.byref(d))
+    if sk > 1:
+        check(L.bdetr_zero(_p(dw), dw.numel(), _stream()), "zero")
+    check(L.bdetr_conv2d_bwd_weight(_p(x), _p(dy), _p(dw), C.byref(d), sk, _stream()), "conv2d_bwd_weight")
+    return dw
+
+
+# --------------------------------------------------------------------------------------
+# GEMM
+# --------------------------------------------------------------------------------------
+def gemm_raw(I, J, R, a, lda, a_rc, b, ldb, b_rc, c, ldc, *, nb0=1, nb1=1, sa=(0, 0), sb=(0, 0), sc=(0, 0),
+             bias=None, alpha=1.0, act=ACT_NONE, accumulate=False, splitk=1):
+    _chk(a, b, c, bias)
+    g = GemmDesc(I, J, R, nb0, nb1, _p(a), lda, sa[0], sa[1], int(a_rc), _p(b), ldb, sb[0], sb[1], int(b_rc),
+                 _p(c), ldc, sc[0], sc[1], _p(bias), float(alpha), act, int(accumulate), splitk)
+    check(_lib.lib().bdetr_gemm(C.byref(g), _stream()), "gemm")
+    return c
+
+
+def linear_fwd(x2d, w, bias, act=ACT_NONE):
+    """y[m][o] = act(sum_i x[m][i] * w[o][i] + bias[o]);  w is [out][in]."""
+    M, K = x2d.shape
+    O = w.shape[0]
+    y = empty(M, O, like=x2d)
+    return gemm_raw(M, O, K, x2d, K, True, w, K, True, y, O, bias=bias, act=act)
+
+
+def linear_bwd_data(dy2d, w, dx=None, accumulate=False):
+    """dx[m][i] = sum_o dy[m][o] * w[o][i]."""
+    M, O = dy2d.shape
+    K = w.shape[1]
+    if dx is None:
+        dx = empty(M, K, like=dy2d)
+    return gemm_raw(M, K, O, dy2d, O, True, w, K, False, dx, K, accumulate=accumulate)
+
+
+def _auto_splitk(I, J, R) -> int:
+    cus = _lib.lib().bdetr_device_cus()
+    tiles = max(1, ((I + 63) // 64) * ((J + 63) // 64))
+    sk = max(1, min((2 * cus + tiles - 1) // tiles, R // 128))
+    return sk
+
+
+def linear_bwd_weight(dy2d, x2d, dw=None):
+    """dw[o][i] = sum_m dy[m][o] * x[m][i]."""
+    M, O = dy2d.shape
+    K = x2d.shape[1]
+    if dw is None:
+        dw = empty(O, K, like=dy2d)
+    sk = _auto_splitk(O, K, M)
+    if sk > 1:
+        check(_lib.lib().bdetr_zero(_p(dw), dw.numel(), _stream()), "zero")
+    return gemm_raw(O, K, M, dy2d, O, False, x2d, K, False, dw, K, splitk=sk)
+
+
+def colsum(x2d, out=None):
+    _chk(x2d, out)
+    L = _lib.lib()
+    rows, cols = x2d.shape
+    if out is None:
+        out = empty(cols, like=x2d)
+    ws = empty(L.bdetr_colsum_chunks(rows) * cols, like=x2d)
+    check(L.bdetr_colsum(_p(x2d), rows, cols, _p(out), _p(ws), _stream()), "colsum")
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# BatchNorm
+# --------------------------------------------------------------------------------------
+def colstats(x2d):
+    _chk(x2d)
+    L = _lib.lib()
+    rows, Cc = x2d.shape
+    n = L.bdetr_bn_bwd_chunks(rows)
+    psum, psq = empty(n, Cc, like=x2d), empty(n, Cc, like=x2d)
+    check(L.bdetr_colstats(_p(x2d), rows, Cc, _p(psum), _p(psq), _stream()), "colstats")
+    return psum, psq, n
+
+
+def bn_stats(rows, Cc, parts, eps, momentum, bessel, moving_mean, moving_var, like):
+    psum, psq, n = parts
+    mean, rstd = empty(Cc, like=like), empty(Cc, like=like)
+    check(_lib.lib().bdetr_bn_stats(None, rows, Cc, _p(psum), _p(psq), n, eps, momentum, int(bessel), _p(mean), _p(rstd),
+                                    _p(moving_mean), _p(moving_var), _stream()), "bn_stats")
+    return mean, rstd
+
+
+def bn_stats_frozen(moving_mean, moving_var, eps):
+    _chk(moving_mean, moving_var)
+    Cc = moving_mean.numel()
+    mean, rstd = empty(Cc, like=moving_mean), empty(Cc, like=moving_mean)
+    check(_lib.lib().bdetr_bn_stats_frozen(_p(moving_mean), _p(moving_var), Cc, eps, _p(mean), _p(rstd), _stream()), "bn_stats_frozen")
+    return mean, rstd
+
+
+def bn_apply(x2d, mean, rstd, gamma, beta, residual=None, relu=False, out=None):
+    _chk(x2d, mean, rstd, gamma, beta, residual, out)
+    rows, Cc = x2d.shape
+    if out is None:
+        out = torch.empty_like(x2d)
+    check(_lib.lib().bdetr_bn_apply(_p(x2d), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(residual), int(relu), _p(out), rows, Cc, _stream()),
+          "bn_apply")
+    return out
+
+
+def bn_bwd(dout, out, x2d, mean, rstd, gamma, relu, frozen, want_residual_grad=False):
+    _chk(dout, out, x2d, mean, rstd, gamma)
+    L = _lib.lib()
+    rows, Cc = x2d.shape
+    dx = torch.empty_like(x2d)
+    dgamma, dbeta = empty(Cc, like=x2d), empty(Cc, like=x2d)
+    dres = torch.empty_like(x2d) if want_residual_grad else None
+    ws = empty(2 * Cc * L.bdetr_bn_bwd_chunks(rows), like=x2d)
+    check(L.bdetr_bn_bwd(_p(dout), _p(out), _p(x2d), _p(mean), _p(rstd), _p(gamma), int(relu), int(frozen), _p(dx), _p(dgamma), _p(dbeta),
+                         _p(dres), _p(ws), rows, Cc, _stream()), "bn_bwd")
+    return dx, dgamma, dbeta, dres
+
+
+# --------------------------------------------------------------------------------------
+# pooling / softmax / layernorm / activations
+# --------------------------------------------------------------------------------------
+def maxpool_fwd(x):
+    _chk(x)
+    N, H, W, Cc = x.shape
+    OH, OW = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    y = empty(N, OH, OW, Cc, like=x)
+    check(_lib.lib().bdetr_maxpool3x3s2_fwd(_p(x), _p(y), N, H, W, Cc, OH, OW, _stream()), "maxpool_fwd")
+    return y
+
+
+def maxpool_bwd(x, y, dy):
+    _chk(x, y, dy)
+    N, H, W, Cc = x.shape
+    _, OH, OW, _ = y.shape
+    dx = torch.empty_like(x)
+    check(_lib.lib().bdetr_maxpool3x3s2_bwd(_p(x), _p(y), _p(dy), _p(dx), N, H, W, Cc, OH, OW, _stream()), "maxpool_bwd")
+    return dx
+
+
+def softmax_rows_fwd(s2d, scale=1.0, out=None):
+    _chk(s2d, out)
+    rows, cols = s2d.shape
+    if out is None:
+        out = torch.empty_like(s2d)
+    check(_lib.lib().bdetr_softmax_rows_fwd(_p(s2d), _p(out), rows, cols, scale, _stream()), "softmax_fwd")
+    return out
+
+
+def softmax_rows_bwd(p2d, dp2d, scale=1.0, out=None):
+    _chk(p2d, dp2d, out)
+    rows, cols = p2d.shape
+    if out is None:
+        out = torch.empty_like(p2d)
+    check(_lib.lib().bdetr_softmax_rows_bwd(_p(p2d), _p(dp2d), _p(out), rows, cols, scale, _stream()), "softmax_bwd")
+    return out
+
+
+def add_dropout_layernorm_fwd(x2d, y2d, gamma, beta, eps, rate=0.0, seed=0):
+    _chk(x2d, y2d, gamma, beta)
+    rows, D = x2d.shape
+    out = torch.empty_like(x2d)
+    mean, rstd = empty(rows, like=x2d), empty(rows, like=x2d)
+    check(_lib.lib().bdetr_add_dropout_layernorm_fwd(_p(x2d), _p(y2d), _p(gamma), _p(beta), _p(out), _p(mean), _p(rstd), rows, D, eps, rate,
+                                                     seed, _stream()), "add_dropout_layernorm_fwd")
+    return out, mean, rstd
+
+
+def add_dropout_layernorm_bwd(dout, x2d, y2d, gamma, mean, rstd, rate=0.0, seed=0):
+    _chk(dout, x2d, y2d, gamma, mean, rstd)
+    L = _lib.lib()
+    rows, D = x2d.shape
+    dx, dy = torch.empty_like(x2d), torch.empty_like(x2d)
+    dgamma, dbeta = empty(D, like=x2d), empty(D, like=x2d)
+    ws = empty(2 * D * L.bdetr_ln_bwd_chunks(rows), like=x2d)
+    check(L.bdetr_add_dropout_layernorm_bwd(_p(dout), _p(x2d), _p(y2d), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dy), _p(dgamma), _p(dbeta),
+                                            _p(ws), rows, D, rate, seed, 0, _stream()), "add_dropout_layernorm_bwd")
+    return dx, dy, dgamma, dbeta
+
+
+def _unary(name, x, out=None):
+    _chk(x, out)
+    if out is None:
+        out = torch.empty_like(x)
+    check(getattr(_lib.lib(), name)(_p(x), _p(out), x.numel(), _stream()), name)
+    return out
+
+
+def _binary(name, a, b, out=None):
+    _chk(a, b, out)
+    if out is None:
+        out = torch.empty_like(a)
+    check(getattr(_lib.lib(), name)(_p(a), _p(b), _p(out), a.numel(), _stream()), name)
+    return out
+
+
+def sigmoid_fwd(x): return _unary("bdetr_sigmoid_fwd", x)
+def sigmoid_bwd(y, dy): return _binary("bdetr_sigmoid_bwd", y, dy)
+def boxsigmoid_fwd(x): return _unary("bdetr_boxsigmoid_fwd", x)
+def boxsigmoid_bwd(y, dy): return _binary("bdetr_boxsigmoid_bwd", y, dy)
+def tanh_bwd(y, dy): return _binary("bdetr_tanh_bwd", y, dy)
+def relu_bwd(y, dy): return _binary("bdetr_relu_bwd", y, dy)
+def add(a, b, out=None): return _binary("bdetr_add", a, b, out)
+
+
+def zero_(t):
+    _chk(t)
+    check(_lib.lib().bdetr_zero(_p(t), t.numel(), _stream()), "zero")
+    return t
+
+
+def axpy_(alpha, x, y):
+    _chk(x, y)
+    check(_lib.lib().bdetr_axpy(float(alpha), _p(x), _p(y), x.numel(), _stream()), "axpy")
+    return y
+
+
+def add_bcast_rows(a, row):
+    """a [B, *rest] + row [*rest]"""
+    _chk(a, row)
+    out = torch.empty_like(a)
+    rowlen = row.numel()
+    check(_lib.lib().bdetr_add_bcast_rows(_p(a), _p(row), _p(out), a.numel() // rowlen, rowlen, _stream()), "add_bcast_rows")
+    return out
+
+
+def sum_over_batch(x, n):
+    _chk(x)
+    out = empty(n, like=x)
+    check(_lib.lib().bdetr_sum_over_batch(_p(x), _p(out), x.numel() // n, n, 0, _stream()), "sum_over_batch")
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# set criterion
+# --------------------------------------------------------------------------------------
+def loss_desc(B, M, N, Cc, A, category_weight, attribute_weight, box_weight, exist_weight) -> LossDesc:
+    return LossDesc(B, M, N, Cc, A, category_weight, attribute_weight, box_weight, exist_weight)
+
+
+def cost_matrix(d: LossDesc, cat_pred, att_pred, box_pred, cat_ids, att_hot, bbox, num_objects, components=False):
+    _chk(cat_pred, att_pred, box_pred, att_hot, bbox)
+    _chk(cat_ids, num_objects, dtype=torch.int32)
+    cost = empty(d.B, d.M, d.N, like=cat_pred)
+    comps = [empty(d.B, d.M, d.N, like=cat_pred) for _ in range(3)] if components else [None] * 3
+    check(_lib.lib().bdetr_cost_matrix(C.byref(d), _p(cat_pred), _p(att_pred), _p(box_pred), _p(cat_ids), _p(att_hot), _p(bbox),
+                                       _p(num_objects), _p(cost), _p(comps[0]), _p(comps[1]), _p(comps[2]), _stream()), "cost_matrix")
+    return (cost, comps) if components else cost
+
+
+def lsa(cost, num_objects):
+    _chk(cost)
+    _chk(num_objects, dtype=torch.int32)
+    B, M, N = cost.shape
+    match = empty(B, M, like=cost, dtype=torch.int32)
+    check(_lib.lib().bdetr_lsa(_p(cost), _p(num_objects), B, M, N, _p(match), _stream()), "lsa")
+    return match
+
+
+def match_to_mask(match, N):
+    _chk(match, dtype=torch.int32)
+    B, M = match.shape
+    mask = empty(B, M, N, like=match, dtype=torch.float32)
+    check(_lib.lib().bdetr_match_to_mask(_p(match), _p(mask), B, M, N, _stream()), "match_to_mask")
+    return mask
+
+
+def set_loss(d: LossDesc, cat_pred, att_pred, box_pred, cat_ids, att_hot, bbox, num_objects, match, loss_scale=1.0, want_grads=True):
+    _chk(cat_pred, att_pred, box_pred, att_hot, bbox)
+    _chk(cat_ids, num_objects, match, dtype=torch.int32)
+    losses = empty(6, d.B, like=cat_pred)
+    d_cat = torch.empty_like(cat_pred) if want_grads else None
+    d_att = torch.empty_like(att_pred) if (want_grads and att_pred is not None) else None
+    d_box = torch.empty_like(box_pred) if want_grads else None
+    check(_lib.lib().bdetr_set_loss(C.byref(d), _p(cat_pred), _p(att_pred), _p(box_pred), _p(cat_ids), _p(att_hot), _p(bbox), _p(num_objects),
+                                    _p(match), _p(losses), _p(d_cat), _p(d_att), _p(d_box), float(loss_scale), _stream()), "set_loss")
+    return losses, d_cat, d_att, d_box

@@ -1,0 +1,235 @@
+/* bdetr.h - C ABI of the MI355X-native DETR training-step hot path.
+ *
+ * One shared library, libbdetr.so (built from boosted_detr_amd/csrc with hipcc for
+ * gfx950).  The reference (mvenouziou/Boosted_DETR) exposes no FFI: its seam is
+ * the Keras object surface and all arithmetic is delegated to TensorFlow /
+ * tensorflow_addons / scipy.  Each entry point below therefore cites the
+ * reference CALL SITE (ModelComponents/<file>:<line>) whose third-party op it
+ * replaces.  INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer (HBM) unless named host_*; fp32 unless stated
+ *  - the caller owns every buffer including workspaces; the library allocates nothing
+ *  - `stream` is a hipStream_t passed as void*; all work is stream-ordered, no
+ *    implicit synchronisation, safe to capture into a hipGraph
+ *  - return value: 0 = ok, <0 = argument/shape error, >0 = hipError_t; the message
+ *    is available from bdetr_last_error() (thread-local); nothing throws or aborts
+ *  - activations are NHWC, conv weights are OHWI ([Cout][KH][KW][Cin]), dense
+ *    weights are [out][in]; the Python host converts from/to the Keras layouts
+ *    (HWIO, [in][out]) at set_weights/get_weights time
+ */
+#ifndef BDETR_H
+#define BDETR_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BDETR_ABI_VERSION 1
+
+int         bdetr_abi_version(void);
+const char* bdetr_last_error(void);
+/* number of CUs of the current device (used by the host to size split-K) */
+int         bdetr_device_cus(void);
+
+/* ---- activation codes for the GEMM / conv epilogue ---- */
+enum { BDETR_ACT_NONE = 0, BDETR_ACT_RELU = 1, BDETR_ACT_TANH = 2 };
+
+/* ------------------------------------------------------------------------
+ * K1  image preparation - backbone.py:49-56 (clip, Resizing, convert_image_dtype
+ *     uint8 round trip, resnet50.preprocess_input caffe mode).
+ *     in  : [B,h,w,3] fp32 in [0,1] (any h,w; bilinear half-pixel resize to HxW)
+ *     out : [B,H,W,4] fp32, channels BGR minus mean, 4th channel = 0 (so the 7x7
+ *           stem conv reads 16-byte pixels)
+ * ---------------------------------------------------------------------- */
+int bdetr_image_prep(const float* in, int B, int h, int w, float* out, int H, int W, void* stream);
+
+/* ------------------------------------------------------------------------
+ * K2/K5/K6  MFMA implicit-GEMM family (v_mfma_f32_32x32x2_f32, LDS-staged tiles).
+ * ---------------------------------------------------------------------- */
+typedef struct {
+    int N, H, W, C;          /* input  NHWC  */
+    int K, R, S;             /* output channels, kernel height, kernel width */
+    int stride, pad;         /* symmetric zero padding */
+    int OH, OW;              /* output spatial size */
+} bdetr_conv_desc;
+
+/* conv forward - Keras Conv2D inside keras.applications.ResNet50 (backbone.py:37-38,57)
+ * and BackboneNeck.conv2d_downscaler (backbone.py:76-78).
+ *   y[N,OH,OW,K] = act(conv(x, w) + bias)
+ *   stat_sum/stat_sq (optional, may be NULL): per-row-chunk partial column sums of
+ *   y and y*y, shape [bdetr_conv2d_fwd_stat_chunks(d)][K] each - consumed by bdetr_bn_stats_finalize */
+int bdetr_conv2d_fwd(const float* x, const float* w, const float* bias, float* y,
+                     const bdetr_conv_desc* d, int act, float* stat_sum, float* stat_sq, void* stream);
+/* number of partial-statistics rows bdetr_conv2d_fwd writes for this geometry */
+int bdetr_conv2d_fwd_stat_chunks(const bdetr_conv_desc* d);
+/* dx[N,H,W,C] (+)= conv_transpose(dy, w).  accumulate!=0 adds into dx (residual merge).
+ * For stride>1 only 1x1/pad 0 is supported (Keras ResNet-50 v1 strides its 1x1s) and
+ * the untouched pixels of dx are written as zero unless accumulate. */
+int bdetr_conv2d_bwd_data(const float* dy, const float* w, float* dx,
+                          const bdetr_conv_desc* d, int accumulate, void* stream);
+/* dw[K,R,S,C] = sum over pixels; split-K partials are combined with fp32 atomics, so the
+ * caller must zero dw first when splitk>1 (bdetr_zero).  splitk<=0 = choose automatically. */
+int bdetr_conv2d_bwd_weight(const float* x, const float* dy, float* dw,
+                            const bdetr_conv_desc* d, int splitk, void* stream);
+int bdetr_conv2d_bwd_weight_splitk(const bdetr_conv_desc* d);
+
+/* strided-batched GEMM - tf Dense / tf.linalg.matmul call sites
+ * (transformers.py:41-48,62-65,86,97,101,174-177; prediction_heads.py:40-43,106-110,175-179)
+ *   C[b][i][j] = act(alpha * sum_r A(b,i,r) * B(b,j,r) + bias[j])      (accumulate: C += ...)
+ *   a_rcontig: A(b,i,r) at a + i*lda + r, else at a + r*lda + i           (same for B with j)
+ *   batch index b = b0*nb1 + b1, operand offset = b0*s?0 + b1*s?1
+ *   splitk>1 splits the r range over gridDim.z and combines with atomics (C must be zeroed,
+ *   nb0*nb1 must be 1, bias/act must be off). */
+typedef struct {
+    int I, J, R;
+    int nb0, nb1;
+    const float* a; int64_t lda, sa0, sa1; int a_rcontig;
+    const float* b; int64_t ldb, sb0, sb1; int b_rcontig;
+    float*       c; int64_t ldc, sc0, sc1;
+    const float* bias; float alpha; int act; int accumulate; int splitk;
+} bdetr_gemm_desc;
+int bdetr_gemm(const bdetr_gemm_desc* g, void* stream);
+
+/* column sums: out[j] = sum_i x[i][j]  (bias gradients; Keras autodiff of Dense/Conv bias).
+ * Deterministic two-level reduction; ws: cols * bdetr_colsum_chunks(rows) floats. */
+int bdetr_colsum_chunks(int64_t rows);
+int bdetr_colsum(const float* x, int64_t rows, int cols, float* out, float* ws, void* stream);
+
+/* ------------------------------------------------------------------------
+ * K3  BatchNormalization, training mode (keras BN inside ResNet-50, backbone.py:79-80,
+ *     prediction_heads.py:42,108,177; semantics SURVEY S5).  x is [rows][C].
+ * ---------------------------------------------------------------------- */
+/* partial column sums of x and x*x over row chunks: part_* are [bdetr_bn_bwd_chunks(rows)][C].
+ * (The conv/GEMM epilogue produces the same partials for free - see bdetr_conv2d_fwd.) */
+int bdetr_colstats(const float* x, int64_t rows, int C, float* part_sum, float* part_sq, void* stream);
+/* reduce nparts partial rows (from bdetr_colstats or a conv epilogue) in fp64, fixed order, into
+ * mean[C], rstd[C] (biased variance); if moving_mean!=NULL update the moving statistics
+ * (momentum; bessel!=0 uses the unbiased variance for the moving estimate).  x is unused. */
+int bdetr_bn_stats(const float* x, int64_t rows, int C, const float* part_sum, const float* part_sq,
+                   int nparts, float eps, float momentum, int bessel,
+                   float* mean, float* rstd, float* moving_mean, float* moving_var, void* stream);
+/* inference-mode statistics: mean = moving_mean, rstd = 1/sqrt(moving_var+eps) */
+int bdetr_bn_stats_frozen(const float* moving_mean, const float* moving_var, int C, float eps,
+                          float* mean, float* rstd, void* stream);
+/* out = [relu]( gamma*(x-mean)*rstd + beta [+ residual] ) */
+int bdetr_bn_apply(const float* x, const float* mean, const float* rstd, const float* gamma,
+                   const float* beta, const float* residual, int relu, float* out,
+                   int64_t rows, int C, void* stream);
+/* backward of bn_apply.  dout: gradient w.r.t. out; out: forward output (for the ReLU mask;
+ * may be NULL when relu==0).  Produces dx, dgamma[C], dbeta[C] and, when dresidual!=NULL,
+ * the masked gradient that flows to the residual branch (dresidual may alias dout).
+ * frozen!=0: statistics were constants (inference-mode BN).  ws: 2*C*nchunks floats where
+ * nchunks = bdetr_bn_bwd_chunks(rows). */
+int bdetr_bn_bwd_chunks(int64_t rows);
+int bdetr_bn_bwd(const float* dout, const float* out, const float* x, const float* mean,
+                 const float* rstd, const float* gamma, int relu, int frozen,
+                 float* dx, float* dgamma, float* dbeta, float* dresidual,
+                 float* ws, int64_t rows, int C, void* stream);
+
+/* ------------------------------------------------------------------------
+ * K4  3x3/2 max-pool with 1-pixel zero pad (ResNet-50 pool1_pad + pool1_pool)
+ * ---------------------------------------------------------------------- */
+int bdetr_maxpool3x3s2_fwd(const float* x, float* y, int N, int H, int W, int C, int OH, int OW, void* stream);
+int bdetr_maxpool3x3s2_bwd(const float* x, const float* y, const float* dy, float* dx,
+                           int N, int H, int W, int C, int OH, int OW, void* stream);
+
+/* ------------------------------------------------------------------------
+ * K7  attention softmax (transformers.py:88-94): p = softmax(scale*s) row-wise, in place ok.
+ *     bwd: ds = scale * p * (dp - sum_k dp*p)
+ * ---------------------------------------------------------------------- */
+int bdetr_softmax_rows_fwd(const float* s, float* p, int64_t rows, int cols, float scale, void* stream);
+int bdetr_softmax_rows_bwd(const float* p, const float* dp, float* ds, int64_t rows, int cols, float scale, void* stream);
+
+/* ------------------------------------------------------------------------
+ * K8  residual + dropout + LayerNormalization (transformers.py:135-137,178-180)
+ *     h = x + dropout(y) ; out = gamma*(h-mean)*rstd + beta   (eps 1e-3, biased var)
+ *     dropout: inverted, keep-prob 1-rate, counter-based RNG keyed by (seed, element index);
+ *     rate==0 disables.  hbuf (optional) receives h for the backward pass.
+ * ---------------------------------------------------------------------- */
+int bdetr_add_dropout_layernorm_fwd(const float* x, const float* y, const float* gamma, const float* beta,
+                                    float* out, float* mean, float* rstd, int64_t rows, int D,
+                                    float eps, float rate, uint64_t seed, void* stream);
+/* given dout: dx (gradient to x, = dh), dy (gradient to y, = dh * dropout mask), dgamma, dbeta.
+ * `out` is the forward output (h is recovered as (out-beta)/gamma is NOT used; xhat is
+ * recomputed from x,y,mean,rstd).  ws: 2*D*bdetr_ln_bwd_chunks(rows) floats. */
+int bdetr_ln_bwd_chunks(int64_t rows);
+int bdetr_add_dropout_layernorm_bwd(const float* dout, const float* x, const float* y, const float* gamma,
+                                    const float* mean, const float* rstd, float* dx, float* dy,
+                                    float* dgamma, float* dbeta, float* ws, int64_t rows, int D,
+                                    float rate, uint64_t seed, int accumulate_dx, void* stream);
+
+/* ------------------------------------------------------------------------
+ * K9  head activations (prediction_heads.py:44,60-62,111,127-129,180,197-199)
+ * ---------------------------------------------------------------------- */
+int bdetr_softmax_lastdim_fwd(const float* logits, float* p, int64_t rows, int cols, void* stream);
+int bdetr_softmax_lastdim_bwd(const float* p, const float* dp, float* dlogits, int64_t rows, int cols, void* stream);
+int bdetr_sigmoid_fwd(const float* x, float* y, int64_t n, void* stream);
+int bdetr_sigmoid_bwd(const float* y, const float* dy, float* dx, int64_t n, void* stream);
+/* y = 3*sigmoid(x/100) - 1 */
+int bdetr_boxsigmoid_fwd(const float* x, float* y, int64_t n, void* stream);
+int bdetr_boxsigmoid_bwd(const float* y, const float* dy, float* dx, int64_t n, void* stream);
+
+/* elementwise helpers */
+int bdetr_zero(float* p, int64_t n, void* stream);
+int bdetr_add(const float* a, const float* b, float* out, int64_t n, void* stream);          /* out = a + b */
+int bdetr_add_bcast_rows(const float* a, const float* row, float* out, int64_t rows, int64_t rowlen, void* stream); /* out[r] = a[r] + row (batch broadcast) */
+int bdetr_sum_over_batch(const float* x, float* out, int64_t batch, int64_t n, int accumulate, void* stream);       /* out = sum_b x[b] */
+int bdetr_tanh_bwd(const float* y, const float* dy, float* dx, int64_t n, void* stream);
+int bdetr_relu_bwd(const float* y, const float* dy, float* dx, int64_t n, void* stream);
+int bdetr_axpy(float alpha, const float* x, float* y, int64_t n, void* stream);               /* y += alpha*x */
+
+/* ------------------------------------------------------------------------
+ * K10-K12  set criterion (losses_and_metrics.py:111-161, 176-192, 195-251)
+ *   One workgroup per image.  Inputs:
+ *     cat_pred [B,N,C] probabilities, att_pred [B,N,A], box_pred [B,N,4]
+ *     cat_ids  int32 [B,M] (0=<PAD>), att_hot [B,M,A] multi-hot fp32 (may be NULL if A==0 or
+ *     attribute_weight==0), bbox [B,M,4] COCO format, num_objects int32 [B]
+ *   bdetr_cost_matrix : cost[B,M,N] = 1000*cat + box_w*box + att_w*att  (fp32, summed in the
+ *                       reference's order, line 130); optional component outputs.  Rows
+ *                       m >= num_objects[b] (never read by the matcher, masked out of the loss)
+ *                       are written as 0 when num_objects != NULL
+ *   bdetr_lsa         : exact rectangular shortest-augmenting-path (Crouse / scipy semantics,
+ *                       fp64 in LDS, scipy's scan order and tie rule), rows i<num_objects[b];
+ *                       match[b][m] = assigned prediction index or -1 ;  int32 [B,M]
+ *   bdetr_set_loss    : masked reductions + existence BCE + IoU metric and the gradient of
+ *                       sum_b total_b w.r.t. the three prediction tensors.
+ *                       losses[6][B] = total, category, attribute, box, exist, iou
+ *                       loss_scale multiplies the gradients (1/num_replicas under DP, S14).
+ * ---------------------------------------------------------------------- */
+typedef struct {
+    int B, M, N, C, A;
+    float category_weight, attribute_weight, box_weight, exist_weight;
+} bdetr_loss_desc;
+int bdetr_cost_matrix(const bdetr_loss_desc* d, const float* cat_pred, const float* att_pred,
+                      const float* box_pred, const int32_t* cat_ids, const float* att_hot,
+                      const float* bbox, const int32_t* num_objects, float* cost, float* cost_cat,
+                      float* cost_att, float* cost_box, void* stream);
+int bdetr_lsa(const float* cost, const int32_t* num_objects, int B, int M, int N,
+              int32_t* match, void* stream);
+int bdetr_set_loss(const bdetr_loss_desc* d, const float* cat_pred, const float* att_pred,
+                   const float* box_pred, const int32_t* cat_ids, const float* att_hot,
+                   const float* bbox, const int32_t* num_objects, const int32_t* match,
+                   float* losses, float* d_cat, float* d_att, float* d_box, float loss_scale,
+                   void* stream);
+/* mask[B,M,N] = 1 where match[b][m]==n (MatchingAssignment output, for inspection/tests) */
+int bdetr_match_to_mask(const int32_t* match, float* mask, int B, int M, int N, void* stream);
+
+/* ------------------------------------------------------------------------
+ * K13  optimizer: per-tensor clip-by-norm + Keras SGD(nesterov) (notebook cell 26, S15).
+ *      Multi-tensor: `ptrs` is a device array of ntensors x {w,g,v} pointers, `sizes` the
+ *      element counts; norms: ntensors floats of workspace.
+ *      Work is split in slabs of bdetr_sgd_slab_elems() elements; the host builds the slab
+ *      table once: slab_tensor[nslabs] (owning tensor of each slab) and slab_first[ntensors+1]
+ *      (first slab of each tensor), both int64 on the device.  partial: nslabs floats.
+ *      lr is read from device memory (so a captured graph sees schedule updates). */
+int bdetr_sgd_slab_elems(void);
+int bdetr_sgd_nesterov_clipnorm(const uint64_t* ptrs, const int64_t* sizes, int ntensors,
+                                const int64_t* slab_tensor, const int64_t* slab_first, int nslabs,
+                                float* partial, float* norms, const float* lr, float momentum,
+                                float clipnorm, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BDETR_H */
