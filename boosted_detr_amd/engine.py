@@ -1,0 +1,293 @@
+"""Minimal Keras-style host runtime for the hot path: Variable, Tape (reverse-mode at
+layer granularity), Layer (build/call/get_config/show_summary) and initialisers.
+
+PyTorch tensors are device containers only; every FLOP runs in csrc/ kernels via
+``kernels.py``.  There is no autograd dependency: backward closures are recorded on a Tape
+while ``call(training=True)`` runs and replayed in reverse.
+
+Mirrors the layer surface the reference builds on (``tf.keras.layers.Layer``,
+/root/reference/ModelComponents/*.py): ``build(input_shape)``, ``call(list_of_tensors,
+training=)``, ``get_config()``, ``show_summary()``, ``.trainable``.
+"""
+from __future__ import annotations
+
+import math
+import zlib
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import kernels as K
+
+_DEVICE = None
+
+
+def device() -> torch.device:
+    global _DEVICE
+    if _DEVICE is None:
+        if not torch.cuda.is_available():
+            raise RuntimeError("boosted_detr_amd needs an AMD GPU (HIP device); there is no CPU execution path")
+        _DEVICE = torch.device("cuda", torch.cuda.current_device())
+    return _DEVICE
+
+
+def to_device(a, dtype=torch.float32) -> torch.Tensor:
+    if isinstance(a, torch.Tensor):
+        return a.to(device=device(), dtype=dtype).contiguous()
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device=device(), dtype=dtype).contiguous()
+
+
+# ----------------------------------------------------------------------------------------
+# variables
+# ----------------------------------------------------------------------------------------
+class Variable:
+    """A model weight.  ``value`` is held in the kernels' layout (conv OHWI, dense [out][in]);
+    ``numpy()`` / ``assign()`` speak the Keras layout (HWIO, [in][out])."""
+
+    def __init__(self, name: str, keras_shape: Sequence[int], kind: str = "vector", trainable: bool = True,
+                 pad_in_channels: int = 0):
+        self.name = name
+        self.keras_shape = tuple(int(s) for s in keras_shape)
+        self.kind = kind
+        self.trainable = trainable
+        self.pad_in_channels = pad_in_channels      # conv1: 3 -> 4 input channels (zero weights)
+        self.value: Optional[torch.Tensor] = None
+        self.grad: Optional[torch.Tensor] = None
+
+    # layout conversion -----------------------------------------------------------------
+    def _to_internal(self, a: np.ndarray) -> np.ndarray:
+        a = np.asarray(a, np.float32)
+        assert tuple(a.shape) == self.keras_shape, (self.name, a.shape, self.keras_shape)
+        if self.kind == "conv_kernel":
+            a = np.transpose(a, (3, 0, 1, 2))            # HWIO -> OHWI
+            if self.pad_in_channels:
+                a = np.concatenate([a, np.zeros(a.shape[:3] + (self.pad_in_channels,), np.float32)], axis=3)
+        elif self.kind == "dense_kernel":
+            a = a.T
+        return np.ascontiguousarray(a)
+
+    def _to_keras(self, a: np.ndarray) -> np.ndarray:
+        if self.kind == "conv_kernel":
+            if self.pad_in_channels:
+                a = a[..., : a.shape[3] - self.pad_in_channels]
+            a = np.transpose(a, (1, 2, 3, 0))
+        elif self.kind == "dense_kernel":
+            a = a.T
+        return np.ascontiguousarray(a)
+
+    def assign(self, keras_array) -> None:
+        t = to_device(self._to_internal(np.asarray(keras_array)))
+        if self.value is None:
+            self.value = t
+        else:
+            self.value.copy_(t)        # keep the storage: optimizer tables hold raw pointers
+
+    def numpy(self) -> np.ndarray:
+        return self._to_keras(self.value.detach().cpu().numpy())
+
+    def grad_numpy(self) -> np.ndarray:
+        return self._to_keras(self.grad.detach().cpu().numpy())
+
+    @property
+    def num_params(self) -> int:
+        return int(np.prod(self.keras_shape))
+
+
+# Keras initialisers -- host-side numpy, seeded per variable name
+def _seed_for(name: str, seed: int) -> int:
+    return (zlib.crc32(name.encode()) ^ (seed * 0x9E3779B1)) & 0xFFFFFFFF
+
+
+def _fans(shape):
+    if len(shape) == 2:
+        return shape[0], shape[1]
+    rf = int(np.prod(shape[:-2]))
+    return shape[-2] * rf, shape[-1] * rf
+
+
+def initializer(kind: str) -> Callable:
+    def trunc_normal(rng, shape, std):
+        out = rng.standard_normal(shape)
+        bad = np.abs(out) > 2.0
+        while bad.any():
+            out[bad] = rng.standard_normal(int(bad.sum()))
+            bad = np.abs(out) > 2.0
+        return (out * std / 0.87962566103423978).astype(np.float32)
+
+    def init(name, shape, seed=0):
+        rng = np.random.Generator(np.random.PCG64(_seed_for(name, seed)))
+        fan_in, fan_out = _fans(shape) if len(shape) >= 2 else (shape[0], shape[0])
+        if kind == "zeros":
+            return np.zeros(shape, np.float32)
+        if kind == "ones":
+            return np.ones(shape, np.float32)
+        if kind == "glorot_normal":
+            return trunc_normal(rng, shape, math.sqrt(2.0 / (fan_in + fan_out)))
+        if kind == "he_normal":
+            return trunc_normal(rng, shape, math.sqrt(2.0 / fan_in))
+        if kind == "lecun_normal":
+            return trunc_normal(rng, shape, math.sqrt(1.0 / fan_in))
+        if kind == "glorot_uniform":
+            lim = math.sqrt(6.0 / (fan_in + fan_out))
+            return rng.uniform(-lim, lim, size=shape).astype(np.float32)
+        raise ValueError(kind)
+
+    return init
+
+
+# ----------------------------------------------------------------------------------------
+# tape
+# ----------------------------------------------------------------------------------------
+class Tape:
+    """Records (outputs, inputs, backward_fn) triples; ``backward`` replays them in reverse and
+    sums gradients that reach the same tensor (residual branches, shared keys/values)."""
+
+    def __init__(self):
+        self.nodes: List[tuple] = []
+
+    def record(self, outputs: Sequence[torch.Tensor], inputs: Sequence[Optional[torch.Tensor]], fn: Callable) -> None:
+        self.nodes.append((tuple(outputs), tuple(inputs), fn))
+
+    def backward(self, seeds: Dict[int, torch.Tensor]) -> Dict[int, torch.Tensor]:
+        grads: Dict[int, torch.Tensor] = dict(seeds)
+        for outputs, inputs, fn in reversed(self.nodes):
+            gouts = [grads.pop(id(o), None) for o in outputs]
+            if all(g is None for g in gouts):
+                continue
+            gins = fn(*gouts)
+            if not isinstance(gins, (tuple, list)):
+                gins = (gins,)
+            assert len(gins) == len(inputs), (len(gins), len(inputs))
+            for t, g in zip(inputs, gins):
+                if t is None or g is None:
+                    continue
+                key = id(t)
+                if key in grads:
+                    grads[key] = K.add(grads[key], g.view(grads[key].shape))
+                else:
+                    grads[key] = g
+        return grads
+
+
+_TAPE: Optional[Tape] = None
+
+
+def current_tape() -> Optional[Tape]:
+    return _TAPE
+
+
+class recording:
+    def __init__(self, tape: Optional[Tape]):
+        self.tape = tape
+
+    def __enter__(self):
+        global _TAPE
+        self.prev = _TAPE
+        _TAPE = self.tape
+        return self.tape
+
+    def __exit__(self, *exc):
+        global _TAPE
+        _TAPE = self.prev
+        return False
+
+
+# ----------------------------------------------------------------------------------------
+# layers
+# ----------------------------------------------------------------------------------------
+class Layer:
+    def __init__(self, name: Optional[str] = None, **kwargs):
+        self.name = name or type(self).__name__
+        self.built = False
+        self._trainable = True
+        self._variables: List[Variable] = []
+        self._sublayers: List["Layer"] = []
+        self._init_seed = int(kwargs.get("seed", 0))
+        self.scope_prefix = kwargs.get("scope_prefix", "")   # parent scope, e.g. "DecoderBlock_1/"
+
+    # attribute tracking (Keras-style: assigning a Layer or a list of Layers registers it)
+    def __setattr__(self, key, value):
+        if isinstance(value, Layer) and key not in ("_parent",):
+            self.__dict__.setdefault("_sublayers", []).append(value)
+        elif isinstance(value, list) and value and all(isinstance(v, Layer) for v in value):
+            self.__dict__.setdefault("_sublayers", []).extend(value)
+        object.__setattr__(self, key, value)
+
+    def track(self, layer: "Layer") -> "Layer":
+        """Register a sub-layer appended to a list attribute after the attribute was assigned."""
+        if layer not in self._sublayers:
+            self._sublayers.append(layer)
+        return layer
+
+    @property
+    def trainable(self) -> bool:
+        return self._trainable
+
+    @trainable.setter
+    def trainable(self, v: bool) -> None:
+        self._trainable = bool(v)
+        for l in self._sublayers:
+            l.trainable = v
+
+    def add_weight(self, name: str, shape, initializer_name: str = "zeros", kind: str = "vector", trainable: bool = True,
+                   value: Optional[np.ndarray] = None, pad_in_channels: int = 0) -> Variable:
+        v = Variable(f"{self.scope}/{name}", shape, kind=kind, trainable=trainable, pad_in_channels=pad_in_channels)
+        v.assign(value if value is not None else initializer(initializer_name)(v.name, tuple(shape), self._init_seed))
+        v.owner = self
+        self._variables.append(v)
+        return v
+
+    scope_prefix = ""
+
+    @property
+    def scope(self) -> str:
+        return f"{self.scope_prefix}{self.name}"
+
+    def layers(self) -> List["Layer"]:
+        out = []
+        for l in self._sublayers:
+            if l not in out:
+                out.append(l)
+        return out
+
+    @property
+    def variables(self) -> List[Variable]:
+        out = list(self._variables)
+        for l in self.layers():
+            for v in l.variables:
+                if v not in out:
+                    out.append(v)
+        return out
+
+    @property
+    def trainable_variables(self) -> List[Variable]:
+        return [v for v in self.variables if v.trainable and getattr(v, "owner", self).trainable]
+
+    def count_params(self) -> int:
+        return sum(v.num_params for v in self.variables)
+
+    def build(self, input_shape) -> None:
+        pass
+
+    def call(self, inputs, training: bool = False):
+        raise NotImplementedError
+
+    def __call__(self, inputs, training: bool = False, **kwargs):
+        if not self.built:
+            shapes = [tuple(t.shape) for t in inputs] if isinstance(inputs, (list, tuple)) else inputs
+            self.build(shapes)
+            self.built = True
+        return self.call(inputs, training=training, **kwargs)
+
+    def get_config(self) -> dict:
+        return {"name": self.name, "trainable": self.trainable}
+
+    def show_summary(self) -> str:
+        lines = [f'Layer "{self.name}" ({type(self).__name__})']
+        for v in self.variables:
+            lines.append(f"  {v.name:80s} {str(v.keras_shape):>22s} {v.num_params:>12,d}{'' if v.trainable else '  (non-trainable)'}")
+        lines.append(f"  total params: {self.count_params():,d}")
+        text = "\n".join(lines)
+        print(text)
+        return text

@@ -1,0 +1,353 @@
+"""The sliver of the Keras training runtime the reference's notebooks use: Model
+(compile / fit / train_step / test_step / save_weights / load_weights / summary), the SGD
+(Nesterov, per-tensor clipnorm) optimizer, CosineDecayRestarts, callbacks, and the
+data-parallel gradient all-reduce (RCCL through torch.distributed).
+
+Reference usage being mirrored: DETR_COCO.ipynb cells 26, 30, 35 (compile(optimizer=...),
+fit(ds, epochs, validation_data, callbacks=[ModelCheckpoint, TerminateOnNaN, TensorBoard]),
+load_weights(latest_checkpoint)); semantics SURVEY S14/S15.
+"""
+from __future__ import annotations
+
+import glob
+import math
+import os
+import time
+from typing import Dict, Iterable, List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import kernels as K
+from . import ops
+from .engine import Layer, Tape, Variable, device, recording, to_device
+
+
+# ----------------------------------------------------------------------------------------
+# learning-rate schedules
+# ----------------------------------------------------------------------------------------
+class CosineDecayRestarts:
+    """tf.keras.optimizers.schedules.CosineDecayRestarts (notebook cell 26:
+    CosineDecayRestarts(1e-3, 4000, m_mul=.95, alpha=.1))."""
+
+    def __init__(self, initial_learning_rate, first_decay_steps, t_mul=2.0, m_mul=1.0, alpha=0.0):
+        self.initial_learning_rate = float(initial_learning_rate)
+        self.first_decay_steps = float(first_decay_steps)
+        self.t_mul, self.m_mul, self.alpha = float(t_mul), float(m_mul), float(alpha)
+
+    def __call__(self, step: int) -> float:
+        completed = step / self.first_decay_steps
+        if self.t_mul == 1.0:
+            i_restart = math.floor(completed)
+            completed -= i_restart
+        else:
+            i_restart = math.floor(math.log(1.0 - completed * (1.0 - self.t_mul)) / math.log(self.t_mul))
+            sum_r = (1.0 - self.t_mul ** i_restart) / (1.0 - self.t_mul)
+            completed = (completed - sum_r) / self.t_mul ** i_restart
+        m_fac = self.m_mul ** i_restart
+        cosine = 0.5 * m_fac * (1.0 + math.cos(math.pi * completed))
+        return self.initial_learning_rate * ((1 - self.alpha) * cosine + self.alpha)
+
+
+# ----------------------------------------------------------------------------------------
+# optimizer
+# ----------------------------------------------------------------------------------------
+class SGD:
+    """Keras SGD(momentum, nesterov=True, clipnorm) as one fused multi-tensor HIP launch
+    (csrc/optim.hip).  Gradients live in one flat HBM buffer so the data-parallel all-reduce
+    moves a few large buckets."""
+
+    def __init__(self, learning_rate=0.01, momentum=0.0, nesterov=False, clipnorm=None, name="SGD"):
+        self.learning_rate = learning_rate
+        self.momentum = float(momentum)
+        self.nesterov = bool(nesterov)
+        self.clipnorm = float(clipnorm) if clipnorm else 0.0
+        self.iterations = 0
+        self._built_for = None
+        if not self.nesterov and self.momentum != 0.0:
+            raise NotImplementedError("the hot path's optimizer is SGD(momentum, nesterov=True); plain momentum is not built")
+
+    def current_lr(self) -> float:
+        lr = self.learning_rate
+        return float(lr(self.iterations)) if callable(lr) else float(lr)
+
+    def build(self, variables: List[Variable]) -> None:
+        dev = device()
+        self.vars = list(variables)
+        sizes = [v.value.numel() for v in self.vars]
+        offs = np.concatenate([[0], np.cumsum([(s + 3) // 4 * 4 for s in sizes])])      # 16-byte aligned slots
+        self.flat_grad = torch.zeros(int(offs[-1]), dtype=torch.float32, device=dev)
+        self.flat_mom = torch.zeros(int(offs[-1]), dtype=torch.float32, device=dev)
+        self.grad_views = [self.flat_grad[int(o): int(o) + s].view(v.value.shape) for o, s, v in zip(offs[:-1], sizes, self.vars)]
+        mom_views = [self.flat_mom[int(o): int(o) + s] for o, s in zip(offs[:-1], sizes)]
+        ptrs = np.zeros((len(self.vars), 3), np.uint64)
+        for i, v in enumerate(self.vars):
+            ptrs[i] = (v.value.data_ptr(), self.grad_views[i].data_ptr(), mom_views[i].data_ptr())
+        slab = _lib.lib().bdetr_sgd_slab_elems()
+        slab_tensor, slab_first = [], [0]
+        for i, s in enumerate(sizes):
+            n = (s + slab - 1) // slab
+            slab_tensor += [i] * n
+            slab_first.append(slab_first[-1] + n)
+        self.nslabs = len(slab_tensor)
+        self.d_ptrs = to_device(ptrs.view(np.int64).reshape(-1), torch.int64)
+        self.d_sizes = to_device(np.asarray(sizes, np.int64), torch.int64)
+        self.d_slab_tensor = to_device(np.asarray(slab_tensor, np.int64), torch.int64)
+        self.d_slab_first = to_device(np.asarray(slab_first, np.int64), torch.int64)
+        self.d_partial = torch.empty(self.nslabs, dtype=torch.float32, device=dev)
+        self.d_norms = torch.empty(len(self.vars), dtype=torch.float32, device=dev)
+        self.d_lr = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._built_for = [id(v) for v in self.vars]
+
+    def stage_gradients(self, variables: List[Variable]) -> None:
+        """Copy the per-variable gradients produced by the backward kernels into the flat buffer."""
+        if self._built_for != [id(v) for v in variables]:
+            self.build(variables)
+        for v, gv in zip(self.vars, self.grad_views):
+            if v.grad is None:
+                K.zero_(gv.view(-1)) if gv.is_contiguous() else gv.zero_()
+            else:
+                gv.copy_(v.grad.view(gv.shape))          # D2D memcpy (plumbing)
+            v.grad = gv
+
+    def apply_gradients(self, grad_scale: float = 1.0) -> None:
+        self.d_lr.fill_(self.current_lr())
+        st = torch.cuda.current_stream().cuda_stream
+        _lib.check(_lib.lib().bdetr_sgd_nesterov_clipnorm(
+            self.d_ptrs.data_ptr(), self.d_sizes.data_ptr(), len(self.vars), self.d_slab_tensor.data_ptr(),
+            self.d_slab_first.data_ptr(), self.nslabs, self.d_partial.data_ptr(), self.d_norms.data_ptr(),
+            self.d_lr.data_ptr(), self.momentum, self.clipnorm, float(grad_scale), st), "sgd")
+        self.iterations += 1
+
+
+# ----------------------------------------------------------------------------------------
+# data parallelism (one process per GPU; RCCL all-reduce of the flat gradient buffer)
+# ----------------------------------------------------------------------------------------
+class DataParallel:
+    """Replicas keep per-replica BN statistics, matcher and normaliser exactly like the reference
+    under MirroredStrategy (parameters.py:74); the only collective is the gradient all-reduce."""
+
+    BUCKET_ELEMS = 8 * 1024 * 1024      # 32 MB fp32 buckets: few, large collectives for point-to-point xGMI
+
+    def __init__(self):
+        import torch.distributed as dist
+        self.dist = dist
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+
+    def allreduce_(self, flat: torch.Tensor) -> None:
+        if self.world == 1:
+            return
+        handles = []
+        for o in range(0, flat.numel(), self.BUCKET_ELEMS):
+            handles.append(self.dist.all_reduce(flat[o: o + self.BUCKET_ELEMS], op=self.dist.ReduceOp.SUM, async_op=True))
+        for h in handles:
+            h.wait()
+
+    def broadcast_variables(self, variables: List[Variable]) -> None:
+        if self.world == 1:
+            return
+        for v in variables:
+            self.dist.broadcast(v.value, src=0)
+
+
+# ----------------------------------------------------------------------------------------
+# callbacks
+# ----------------------------------------------------------------------------------------
+class Callback:
+    def set_model(self, model): self.model = model
+    def on_epoch_end(self, epoch, logs=None): pass
+    def on_batch_end(self, batch, logs=None): pass
+
+
+class TerminateOnNaN(Callback):
+    def on_batch_end(self, batch, logs=None):
+        loss = (logs or {}).get("loss")
+        if loss is not None and not math.isfinite(loss):
+            print(f"Batch {batch}: Invalid loss, terminating training")
+            self.model.stop_training = True
+
+
+class ModelCheckpoint(Callback):
+    def __init__(self, filepath, save_weights_only=True, **kwargs):
+        self.filepath, self.save_weights_only = filepath, save_weights_only
+
+    def on_epoch_end(self, epoch, logs=None):
+        path = self.filepath.format(epoch=epoch + 1, **(logs or {}))
+        self.model.save_weights(path)
+
+
+class TensorBoard(Callback):
+    """Writes scalar logs as JSON lines (the TF event format needs TensorFlow, which is absent)."""
+
+    def __init__(self, log_dir="logs", **kwargs):
+        self.log_dir = log_dir
+
+    def on_epoch_end(self, epoch, logs=None):
+        import json
+        os.makedirs(self.log_dir, exist_ok=True)
+        with open(os.path.join(self.log_dir, "scalars.jsonl"), "a") as f:
+            f.write(json.dumps({"epoch": epoch, **{k: float(v) for k, v in (logs or {}).items()}}) + "\n")
+
+
+def latest_checkpoint(checkpoint_dir: str) -> Optional[str]:
+    files = sorted(glob.glob(os.path.join(checkpoint_dir, "*.safetensors")), key=os.path.getmtime)
+    return files[-1] if files else None
+
+
+# ----------------------------------------------------------------------------------------
+# Model
+# ----------------------------------------------------------------------------------------
+class Model(Layer):
+    def __init__(self, name=None, **kwargs):
+        super().__init__(name=name, **kwargs)
+        self.optimizer: Optional[SGD] = None
+        self.stop_training = False
+        self._step_losses: List[torch.Tensor] = []      # [B] vectors handed to add_loss
+        self._loss_roots: List[torch.Tensor] = []       # tape roots whose backward seeds the step
+        self._step_metrics: Dict[str, torch.Tensor] = {}
+        self._dp: Optional[DataParallel] = None
+        self.steps_done = 0
+
+    # -- Keras bookkeeping -----------------------------------------------------------------
+    def add_loss(self, loss) -> None:
+        self._step_losses.append(loss)
+
+    def add_metric(self, value, name) -> None:
+        self._step_metrics[name] = value
+
+    @property
+    def losses(self):
+        return list(self._step_losses)
+
+    @property
+    def metrics_names(self):
+        return ["loss"] + list(self._step_metrics)
+
+    def compile(self, optimizer=None, **kwargs) -> None:
+        if kwargs.get("loss") is not None:
+            raise NotImplementedError("the reference compiles without a loss (losses are built into the model, model.py:208)")
+        self.optimizer = optimizer
+
+    def distribute(self) -> "Model":
+        """Enable data parallelism over the initialised torch.distributed (RCCL) process group."""
+        self._dp = DataParallel()
+        self.loss_fn.loss_scale = 1.0 / self._dp.world     # S14: per-replica loss scaled by 1/num_replicas
+        return self
+
+    # -- one step ----------------------------------------------------------------------------
+    def forward_backward(self, data: dict):
+        """forward + matcher + loss + backward.  Leaves gradients in Variable.grad."""
+        self._step_losses, self._loss_roots, self._step_metrics = [], [], {}
+        ops.set_dropout_seed(0x5EED + self.steps_done)
+        tape = Tape()
+        with recording(tape):
+            y_pred = self(data, training=True)
+        grads = tape.backward({id(t): t for t in self._loss_roots})
+        for v in self.variables:
+            v.grad = grads.get(id(v.value)) if v.trainable else None
+        return y_pred
+
+    def train_step(self, data: dict) -> Dict[str, torch.Tensor]:
+        if self.optimizer is None:
+            raise RuntimeError("call compile(optimizer=...) before fit/train_step")
+        self.forward_backward(data)
+        tv = self.trainable_variables
+        self.optimizer.stage_gradients(tv)
+        if self._dp is not None:
+            self._dp.allreduce_(self.optimizer.flat_grad)
+        self.optimizer.apply_gradients()
+        self.steps_done += 1
+        return self.step_logs()
+
+    def test_step(self, data):
+        return self.train_step(data)        # model.py:235-236: validation also trains (quirk kept)
+
+    def step_logs(self) -> Dict[str, list]:
+        """name -> list of per-image [B] device tensors (one per weak learner).  Nothing is copied to
+        the host here; ``logs_to_host`` does the Keras-style reduction ('loss' = mean over the batch
+        of the summed [B] vectors) when somebody actually wants to read the numbers."""
+        logs = {"loss": list(self._step_losses)}
+        logs.update({k: list(v) for k, v in self._step_metrics.items()})
+        return logs
+
+    @staticmethod
+    def logs_to_host(logs: Dict[str, list]) -> Dict[str, float]:
+        return {k: float(sum(t.detach().cpu().numpy().astype(np.float64) for t in v).mean()) for k, v in logs.items() if v}
+
+    def fit(self, x: Iterable[dict], epochs: int = 1, validation_data: Optional[Iterable[dict]] = None,
+            callbacks: Optional[list] = None, steps_per_epoch: Optional[int] = None, verbose: int = 1):
+        callbacks = callbacks or []
+        for cb in callbacks:
+            cb.set_model(self)
+        history = {"loss": []}
+        self.stop_training = False
+        for epoch in range(epochs):
+            t0, n, sums = time.time(), 0, {}
+            for step, batch in enumerate(x):
+                if steps_per_epoch is not None and step >= steps_per_epoch:
+                    break
+                logs = self.logs_to_host(self.train_step(batch))                     # sync point: host logging
+                for k, v in logs.items():
+                    sums[k] = sums.get(k, 0.0) + v
+                n += 1
+                for cb in callbacks:
+                    cb.on_batch_end(step, logs)
+                if self.stop_training:
+                    break
+            epoch_logs = {k: v / max(n, 1) for k, v in sums.items()}
+            if validation_data is not None and not self.stop_training:
+                vs, vn = {}, 0
+                for batch in validation_data:
+                    for k, v in self.logs_to_host(self.test_step(batch)).items():
+                        vs[k] = vs.get(k, 0.0) + v
+                    vn += 1
+                epoch_logs.update({f"val_{k}": v / max(vn, 1) for k, v in vs.items()})
+            history["loss"].append(epoch_logs.get("loss"))
+            if verbose:
+                msg = " - ".join(f"{k}: {v:.4f}" for k, v in epoch_logs.items())
+                print(f"Epoch {epoch + 1}/{epochs} - {time.time() - t0:.1f}s - {n} steps - {msg}")
+            for cb in callbacks:
+                cb.on_epoch_end(epoch, epoch_logs)
+            if self.stop_training:
+                break
+        return history
+
+    # -- weights -----------------------------------------------------------------------------
+    def get_weights_dict(self) -> Dict[str, np.ndarray]:
+        return {v.name: v.numpy() for v in self.variables}
+
+    def set_weights_dict(self, weights: Dict[str, np.ndarray], strict: bool = True) -> None:
+        names = {v.name for v in self.variables}
+        if strict:
+            missing, extra = names - set(weights), set(weights) - names
+            if missing or extra:
+                raise KeyError(f"weight name mismatch: missing {sorted(missing)[:5]} extra {sorted(extra)[:5]}")
+        for v in self.variables:
+            if v.name in weights:
+                v.assign(weights[v.name])
+
+    def save_weights(self, filepath: str) -> None:
+        from safetensors.numpy import save_file
+        if not filepath.endswith(".safetensors"):
+            filepath += ".safetensors"
+        os.makedirs(os.path.dirname(os.path.abspath(filepath)), exist_ok=True)
+        save_file({k: np.ascontiguousarray(v) for k, v in self.get_weights_dict().items()}, filepath)
+
+    def load_weights(self, filepath: str) -> None:
+        from safetensors.numpy import load_file
+        if not filepath.endswith(".safetensors"):
+            filepath += ".safetensors"
+        self.set_weights_dict(load_file(filepath))
+
+    def summary(self) -> str:
+        lines = [f'Model: "{self.name}"', "-" * 96]
+        for l in self.layers():
+            lines.append(f"{l.name:48s} {type(l).__name__:32s} {l.count_params():>12,d}")
+        total = self.count_params()
+        train = sum(v.num_params for v in self.trainable_variables)
+        lines += ["-" * 96, f"Total params: {total:,d}", f"Trainable params: {train:,d}", f"Non-trainable params: {total - train:,d}"]
+        text = "\n".join(lines)
+        print(text)
+        return text
