@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Training-step benchmark of the DETR hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = image preparation -> ResNet-50 -> neck -> 6 encoder + 6 decoder layers -> heads ->
+cost matrix -> on-GPU LSA -> set-criterion loss -> full backward -> (RCCL gradient all-reduce
+when N>1) -> SGD-Nesterov/clipnorm update, on one synthetic COCO-shaped batch that is resident in
+HBM before the timed region.  Workload = BASELINE.json configs[1] (per GPU: batch 16, 640x640,
+d=256 h=8, 100 queries, COCO-80 classes, dropout 0.1 like the reference).  Rank 0 prints ONE JSON
+line.  `value` is whole-job images/s (global batch / max-over-ranks step time).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+METRIC = "images/sec training step (fwd+matcher+loss+bwd), 640x640 N=100"
+PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)
+GFLOP_PER_IMAGE = 201.7                # 3 x fwd - conv1 bwd-data at 640^2, 6+6, N=100
+
+
+def synthetic_batch(cfg_mod, cfg, batch, max_objects, seed):
+    return cfg_mod.make_batch(cfg, batch, max_objects, seed=seed)
+
+
+def make_batch(B, H, W, M, C, seed):
+    """SURVEY 8(d) synthetic inputs (same generator as oracle.make_batch, restated here so the
+    timed path never imports the oracle)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    image = rng.random((B, H, W, 3), dtype=np.float32)
+    num_objects = np.clip(1 + rng.poisson(6.3, size=B), 1, min(93, M)).astype(np.int32)
+    category = np.zeros((B, M), np.int32)
+    attribute = np.zeros((B, M, 3), np.int32)
+    bbox = np.full((B, M, 4), -10.0, np.float32)
+    for b in range(B):
+        n = int(num_objects[b])
+        category[b, :n] = rng.integers(2, C, size=n)
+        bbox[b, :n, 0:2] = rng.uniform(0.0, 0.6, size=(n, 2))
+        bbox[b, :n, 2:4] = rng.uniform(0.05, 0.4, size=(n, 2))
+    return {"image": image, "category": category, "attribute": attribute, "bbox": bbox, "num_objects": num_objects}
+
+
+def build_model(args):
+    from boosted_detr_amd import parameters
+    from boosted_detr_amd.model import DETR
+    from boosted_detr_amd.training import SGD, CosineDecayRestarts
+    model = DETR(num_object_preds=args.queries, image_size=(args.image, args.image), num_encoder_blocks=args.layers,
+                 num_encoder_heads=8, encoder_dim=256, num_decoder_blocks=args.layers, num_decoder_heads=8, decoder_dim=256,
+                 num_panoptic_heads=1, panoptic_dim=32, vocab_dict=parameters.COCO_VOCAB, attribute_weight=0.0)
+    # notebook cell 26: SGD(CosineDecayRestarts(1e-3, 4000, m_mul=.95, alpha=.1), momentum=.9, nesterov=True, clipnorm=.1)
+    model.compile(optimizer=SGD(CosineDecayRestarts(1e-3, 4000, m_mul=0.95, alpha=0.1), momentum=0.9, nesterov=True, clipnorm=0.1))
+    return model
+
+
+def usable_cores() -> int:
+    """CPU share of this process: affinity mask, capped by the cgroup quota and by 16 (the GPU box
+    gives one GPU's job 16 cores; os.cpu_count() reports the whole host and oversubscribes)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("BDETR_CPU_THREADS", "16"))))
+
+
+def cpu_baseline(args):
+    """The build's CPU restatement (oracle, PyTorch-CPU fp32 + scipy matcher) timed on the host cores:
+    forward + matcher + loss + backward on a bounded sample of the same workload (batch 2)."""
+    import torch
+    from oracle import detr_oracle as O
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    print(f"[bench] cpu_baseline: torch-CPU oracle on {cores} threads", file=sys.stderr, flush=True)
+    cfg = O.Config(image_size=(args.image, args.image), num_object_preds=args.queries, num_encoder_blocks=args.layers,
+                   num_decoder_blocks=args.layers, num_categories=82, num_attributes=3, attribute_weight=0.0, dropout_rate=0.1)
+    params = O.make_params(cfg, seed=0)
+    B = 2
+    batch = O.make_batch(cfg, B, 100, seed=1234)
+    O.train_step_grads(cfg, params, batch)               # warm-up
+    t0 = time.time()
+    n = 0
+    while n < 2 or (time.time() - t0 < 10.0 and n < 8):
+        O.train_step_grads(cfg, params, batch)
+        n += 1
+    dt = time.time() - t0
+    return {"value": round(B * n / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"config-2 shapes ({args.image}x{args.image}, {args.layers}+{args.layers}, N={args.queries}), batch {B}, 1 warm-up + {n} timed "
+                      f"steps of fwd+scipy matcher+loss+bwd (torch-CPU fp32 oracle, {cores} threads)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (config 2: 16)")
+    ap.add_argument("--image", type=int, default=640)
+    ap.add_argument("--layers", type=int, default=6)
+    ap.add_argument("--queries", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from boosted_detr_amd import _lib
+    from boosted_detr_amd.engine import to_device
+    L = _lib.lib()
+
+    model = build_model(args)
+    host = make_batch(args.batch, args.image, args.image, 100, 82, seed=1234 + rank)
+    # inputs resident in HBM before the timed region (targets are pre-tokenised int ids)
+    batch = {"image": to_device(host["image"]), "category": host["category"], "attribute": host["attribute"],
+             "bbox": to_device(host["bbox"]), "num_objects": to_device(host["num_objects"], torch.int32)}
+    cat_ids, att_hot = model.Tokenization([host["category"], host["attribute"]])
+    model.Tokenization.call = lambda inputs, training=False: (cat_ids, att_hot)      # tokenised once, resident
+
+    if world > 1:
+        model.distribute()
+    def note(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    for i in range(max(args.warmup, 1)):
+        tw = time.perf_counter()
+        model.train_step(batch)
+        torch.cuda.synchronize()
+        note(f"warm-up step {i}: {(time.perf_counter() - tw) * 1e3:.1f} ms")
+    if world > 1:
+        model._dp.broadcast_variables(model.variables)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    want_roof = rank == 0 and not args.no_roofline
+    barrier()
+    if want_roof:
+        L.bdetr_prof_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model.train_step(batch)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    roof = None
+    if want_roof:
+        ms, n, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+        _lib.check(L.bdetr_prof_read(ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)), "prof_read")
+        L.bdetr_prof_enable(0)
+        if ms.value > 0:
+            ach = fl.value / (ms.value * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "kernel": "igemm_kernel (fp32 MFMA implicit-GEMM family: conv fwd/bwd-data/bwd-weight, dense, attention GEMMs)",
+                    "launches_per_step": n.value // args.steps, "kernel_ms_per_step": round(ms.value / args.steps, 3),
+                    "gflop_per_step": round(fl.value / args.steps / 1e9, 1)}
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    note(f"timed {args.steps} steps in {elapsed:.3f} s")
+    if rank == 0:
+        global_batch = args.batch * world
+        ms_per_step = elapsed / args.steps * 1e3
+        value = global_batch * args.steps / elapsed
+        logs = model.logs_to_host(model.step_logs())
+        out = {
+            "metric": METRIC, "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs[1]: DETR ResNet-50 {args.image}x{args.image}, {args.layers} enc + {args.layers} dec, d=256 h=8, "
+                                   f"{args.queries} queries, COCO-80, dropout 0.1, SGD-Nesterov clipnorm step",
+                       "per_gpu_batch": args.batch, "global_batch": global_batch, "parallelism": f"dp{world}",
+                       "gflop_per_image_algorithmic": GFLOP_PER_IMAGE},
+            "tflops_algorithmic": round(value * GFLOP_PER_IMAGE / 1e3, 2),
+            "final_loss": round(logs.get("loss", float("nan")), 4),
+            "roofline": roof,
+            "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(args),
+        }
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -48,6 +48,8 @@ SIGNATURES = {
     "bdetr_abi_version": (I, []),
     "bdetr_last_error": (C.c_char_p, []),
     "bdetr_device_cus": (I, []),
+    "bdetr_prof_enable": (I, [I]),
+    "bdetr_prof_read": (I, [P, P, P]),
     "bdetr_image_prep": (I, [P, I, I, I, P, I, I, P]),
     "bdetr_conv2d_fwd": (I, [P, P, P, P, C.POINTER(ConvDesc), I, P, P, P]),
     "bdetr_conv2d_fwd_stat_chunks": (I, [C.POINTER(ConvDesc)]),

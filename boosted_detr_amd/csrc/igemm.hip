@@ -14,6 +14,8 @@
 // (backbone.py:37-38,76-78; transformers.py:41-48,62-65,86,97,101,174-177;
 //  prediction_heads.py:40-43,106-110,175-179).
 #include "common.h"
+#include <utility>
+#include <vector>
 
 namespace {
 
@@ -348,12 +350,36 @@ TileChoice choose_tile(int I, int J, int zdim) {
     return {64, 64};
 }
 
+// ---- optional live profiling of the MFMA kernel family (bench.py's roofline leg) -----------------
+// When enabled, every igemm launch is bracketed by two hipEvents recorded on the launch stream; the
+// host resolves the elapsed times after the timed region.  Events come from a pool that only grows.
+struct ProfRec { hipEvent_t e0, e1; double flops; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof_recs;
+std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
+size_t g_prof_used = 0;
+
+void prof_begin(hipStream_t st, double flops) {
+    if (g_prof_used == g_prof_pool.size()) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+        g_prof_pool.emplace_back(a, b);
+    }
+    auto& ev = g_prof_pool[g_prof_used++];
+    g_prof_recs.push_back({ev.first, ev.second, flops});
+    hipEventRecord(ev.first, st);
+}
+void prof_end(hipStream_t st) { hipEventRecord(g_prof_recs.back().e1, st); }
+
 template <int BM, int BN, int WM, int WN, class LA, bool A_RC, class LB, bool B_RC>
 int launch_cfg(const typename LA::Op& a, const typename LB::Op& b, GemmParams g, int zdim, hipStream_t st) {
     g.tiles_i = (int)cdiv64(g.I, BM);
     g.tiles_j = (int)cdiv64(g.J, BN);
     dim3 grid(g.tiles_i * g.tiles_j, 1, zdim);
+    const bool prof = g_prof_on;
+    if (prof) prof_begin(st, 2.0 * (double)g.I * (double)g.J * (double)g.R * (g.splitk > 1 ? 1.0 : (double)zdim));
     hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, LA, A_RC, LB, B_RC>), grid, dim3(NTHREADS), 0, st, a, b, g);
+    if (prof) prof_end(st);
     return bdetr_launch_status("igemm");
 }
 
@@ -386,6 +412,27 @@ void init_params(GemmParams& g) {
 // C ABI
 // ----------------------------------------------------------------------------------------
 extern "C" int bdetr_device_cus(void) { return num_cus(); }
+
+extern "C" int bdetr_prof_enable(int on) {
+    g_prof_on = on != 0;
+    if (on) { g_prof_recs.clear(); g_prof_used = 0; }
+    return 0;
+}
+// Resolves all recorded launches (the caller must have synchronised the stream): total kernel time
+// in ms, number of launches and the algorithmic FLOPs they performed (2*I*J*R per GEMM).
+extern "C" int bdetr_prof_read(double* total_ms, int64_t* launches, double* flops) {
+    double ms = 0, fl = 0;
+    for (auto& r : g_prof_recs) {
+        float t = 0.f;
+        hipError_t e = hipEventElapsedTime(&t, r.e0, r.e1);
+        if (e != hipSuccess) { bdetr_set_error("bdetr_prof_read: %s", hipGetErrorString(e)); return (int)e; }
+        ms += t; fl += r.flops;
+    }
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = (int64_t)g_prof_recs.size();
+    if (flops) *flops = fl;
+    return 0;
+}
 
 extern "C" int bdetr_gemm(const bdetr_gemm_desc* d, void* stream) {
     BDETR_CHECK_ARG(d && d->a && d->b && d->c, "bdetr_gemm: null pointer");

@@ -32,6 +32,13 @@ const char* bdetr_last_error(void);
 /* number of CUs of the current device (used by the host to size split-K) */
 int         bdetr_device_cus(void);
 
+/* Live profiling of the MFMA (igemm) kernel family for bench.py's roofline leg: when enabled,
+ * every conv/GEMM launch is bracketed by hipEvents on its own stream.  bdetr_prof_read (after a
+ * stream synchronise) returns the summed kernel time, the launch count and the algorithmic FLOPs
+ * (2*I*J*R per GEMM) of everything launched since bdetr_prof_enable(1). */
+int bdetr_prof_enable(int on);
+int bdetr_prof_read(double* total_ms, int64_t* launches, double* flops);
+
 /* ---- activation codes for the GEMM / conv epilogue ---- */
 enum { BDETR_ACT_NONE = 0, BDETR_ACT_RELU = 1, BDETR_ACT_TANH = 2 };
 
