@@ -173,6 +173,8 @@ def main():
     if want_roof:
         ms, n, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
         _lib.check(L.bdetr_prof_read(ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)), "prof_read")
+        if os.environ.get("BDETR_PROF_DUMP"):
+            L.bdetr_prof_dump(os.environ["BDETR_PROF_DUMP"].encode())
         L.bdetr_prof_enable(0)
         if ms.value > 0:
             ach = fl.value / (ms.value * 1e-3) / 1e12

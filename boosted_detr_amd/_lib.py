@@ -50,6 +50,7 @@ SIGNATURES = {
     "bdetr_device_cus": (I, []),
     "bdetr_prof_enable": (I, [I]),
     "bdetr_prof_read": (I, [P, P, P]),
+    "bdetr_prof_dump": (I, [C.c_char_p]),
     "bdetr_image_prep": (I, [P, I, I, I, P, I, I, P]),
     "bdetr_conv2d_fwd": (I, [P, P, P, P, C.POINTER(ConvDesc), I, P, P, P]),
     "bdetr_conv2d_fwd_stat_chunks": (I, [C.POINTER(ConvDesc)]),
@@ -60,7 +61,8 @@ SIGNATURES = {
     "bdetr_colsum_chunks": (I, [L]),
     "bdetr_colsum": (I, [P, L, I, P, P, P]),
     "bdetr_colstats": (I, [P, L, I, P, P, P]),
-    "bdetr_bn_stats": (I, [P, L, I, P, P, I, F, F, I, P, P, P, P, P]),
+    "bdetr_bn_stats": (I, [P, L, I, P, P, I, F, F, I, P, P, P, P, P, P]),
+    "bdetr_bn_stats_fold_rows": (I, []),
     "bdetr_bn_stats_frozen": (I, [P, P, I, F, P, P, P]),
     "bdetr_bn_apply": (I, [P, P, P, P, P, P, I, P, L, I, P]),
     "bdetr_bn_bwd_chunks": (I, [L]),

@@ -147,12 +147,19 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     __syncthreads();
     if (ry == 0 && c < cols) part[(int64_t)blockIdx.y * cols + c] = s[cx] + s[cx + 64] + s[cx + 128] + s[cx + 192];
 }
+// 32 columns x 8 part-phases per block, fp64, fixed order
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int nparts, int cols, float* __restrict__ out) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= cols) return;
+    __shared__ double s[256];
+    const int cx = threadIdx.x & 31, py = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;
     double a = 0;
-    for (int p = 0; p < nparts; ++p) a += part[(int64_t)p * cols + c];
-    out[c] = (float)a;
+    if (c < cols) for (int p = py; p < nparts; p += 8) a += part[(int64_t)p * cols + c];
+    s[threadIdx.x] = a;
+    __syncthreads();
+    if (py == 0 && c < cols) {
+        for (int k = 1; k < 8; ++k) a += s[cx + 32 * k];
+        out[c] = (float)a;
+    }
 }
 
 template <int OP>
@@ -213,15 +220,20 @@ extern "C" int bdetr_sum_over_batch(const float* x, float* out, int64_t batch, i
     hipLaunchKernelGGL(sum_over_batch_kernel, dim3(ew_grid(n, 256, 1)), dim3(256), 0, (hipStream_t)stream, x, out, batch, n, accumulate);
     return bdetr_launch_status("sum_over_batch");
 }
-extern "C" int bdetr_colsum_chunks(int64_t rows) {
-    int64_t rpc = cdiv64(rows, 256); if (rpc < 64) rpc = 64;
-    return (int)cdiv64(rows, rpc);
+static int64_t colsum_rows_per_chunk(int64_t rows, int cols) {
+    // enough chunks to fill the chip with (cols/64) x nch blocks, at least 32 rows per chunk
+    int64_t colblocks = (cols + 63) / 64;
+    int64_t want = cdiv64(1024, colblocks);
+    int64_t rpc = cdiv64(rows, want);
+    if (rpc < 32) rpc = 32;
+    return rpc;
 }
+extern "C" int bdetr_colsum_chunks(int64_t rows) { return (int)cdiv64(rows, 32); }   // upper bound for any cols
 extern "C" int bdetr_colsum(const float* x, int64_t rows, int cols, float* out, float* ws, void* stream) {
     BDETR_CHECK_ARG(x && out && ws && rows > 0 && cols > 0, "bdetr_colsum: bad arguments");
-    int64_t rpc = cdiv64(rows, 256); if (rpc < 64) rpc = 64;
+    int64_t rpc = colsum_rows_per_chunk(rows, cols);
     int nch = (int)cdiv64(rows, rpc);
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 63) / 64, nch), dim3(256), 0, (hipStream_t)stream, x, rows, cols, rpc, ws);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, nch, cols, out);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 31) / 32), dim3(256), 0, (hipStream_t)stream, ws, nch, cols, out);
     return bdetr_launch_status("colsum");
 }

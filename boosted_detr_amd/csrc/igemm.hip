@@ -353,20 +353,25 @@ TileChoice choose_tile(int I, int J, int zdim) {
 // ---- optional live profiling of the MFMA kernel family (bench.py's roofline leg) -----------------
 // When enabled, every igemm launch is bracketed by two hipEvents recorded on the launch stream; the
 // host resolves the elapsed times after the timed region.  Events come from a pool that only grows.
-struct ProfRec { hipEvent_t e0, e1; double flops; };
+struct ProfRec { hipEvent_t e0, e1; double flops; int I, J, R, z, bm, bn, kind; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof_recs;
 std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
 size_t g_prof_used = 0;
 
-void prof_begin(hipStream_t st, double flops) {
+template <class L> struct LoaderId { static constexpr int v = 0; };
+template <> struct LoaderId<PatchLoader> { static constexpr int v = 1; };
+template <> struct LoaderId<WFlipLoader> { static constexpr int v = 2; };
+template <> struct LoaderId<DenseLoader<1>> { static constexpr int v = 3; };
+
+void prof_begin(hipStream_t st, double flops, int I, int J, int R, int z, int bm, int bn, int kind) {
     if (g_prof_used == g_prof_pool.size()) {
         hipEvent_t a, b;
         if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
         g_prof_pool.emplace_back(a, b);
     }
     auto& ev = g_prof_pool[g_prof_used++];
-    g_prof_recs.push_back({ev.first, ev.second, flops});
+    g_prof_recs.push_back({ev.first, ev.second, flops, I, J, R, z, bm, bn, kind});
     hipEventRecord(ev.first, st);
 }
 void prof_end(hipStream_t st) { hipEventRecord(g_prof_recs.back().e1, st); }
@@ -377,7 +382,8 @@ int launch_cfg(const typename LA::Op& a, const typename LB::Op& b, GemmParams g,
     g.tiles_j = (int)cdiv64(g.J, BN);
     dim3 grid(g.tiles_i * g.tiles_j, 1, zdim);
     const bool prof = g_prof_on;
-    if (prof) prof_begin(st, 2.0 * (double)g.I * (double)g.J * (double)g.R * (g.splitk > 1 ? 1.0 : (double)zdim));
+    if (prof) prof_begin(st, 2.0 * (double)g.I * (double)g.J * (double)g.R * (g.splitk > 1 ? 1.0 : (double)zdim), g.I, g.J, g.R, zdim, BM, BN,
+                         LoaderId<LA>::v * 1000 + (A_RC ? 100 : 0) + LoaderId<LB>::v * 10 + (B_RC ? 1 : 0));
     hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, LA, A_RC, LB, B_RC>), grid, dim3(NTHREADS), 0, st, a, b, g);
     if (prof) prof_end(st);
     return bdetr_launch_status("igemm");
@@ -420,6 +426,20 @@ extern "C" int bdetr_prof_enable(int on) {
 }
 // Resolves all recorded launches (the caller must have synchronised the stream): total kernel time
 // in ms, number of launches and the algorithmic FLOPs they performed (2*I*J*R per GEMM).
+// debug aid: one CSV row per recorded launch (I,J,R,zdim,BM,BN,kind,ms,gflop); kind = LA*1000 + A_RC*100 + LB*10 + B_RC
+extern "C" int bdetr_prof_dump(const char* path) {
+    FILE* f = fopen(path, "w");
+    if (!f) { bdetr_set_error("bdetr_prof_dump: cannot open %s", path); return -1; }
+    fprintf(f, "I,J,R,z,bm,bn,kind,ms,gflop\n");
+    for (auto& r : g_prof_recs) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) t = -1.f;
+        fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%.5f,%.4f\n", r.I, r.J, r.R, r.z, r.bm, r.bn, r.kind, t, r.flops * 1e-9);
+    }
+    fclose(f);
+    return 0;
+}
+
 extern "C" int bdetr_prof_read(double* total_ms, int64_t* launches, double* flops) {
     double ms = 0, fl = 0;
     for (auto& r : g_prof_recs) {

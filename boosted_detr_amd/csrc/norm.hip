@@ -74,6 +74,22 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     }
 }
 
+// [nparts][C] -> [nout][C]: output row o sums input rows o, o+nout, o+2*nout, ... (fixed order)
+__global__ __launch_bounds__(256) void fold_partials2_kernel(const float* __restrict__ pa, const float* __restrict__ pb, int nparts, int C, int nout,
+                                                             float* __restrict__ oa, float* __restrict__ ob) {
+    __shared__ float s1[256], s2[256];
+    const int cx = threadIdx.x & 31, py = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx, o = blockIdx.y;
+    float a = 0.f, b = 0.f;
+    if (c < C) for (int p = o + py * nout; p < nparts; p += 8 * nout) { a += pa[(int64_t)p * C + c]; b += pb[(int64_t)p * C + c]; }
+    s1[threadIdx.x] = a; s2[threadIdx.x] = b;
+    __syncthreads();
+    if (py == 0 && c < C) {
+        for (int k = 1; k < 8; ++k) { a += s1[cx + 32 * k]; b += s2[cx + 32 * k]; }
+        oa[(int64_t)o * C + c] = a; ob[(int64_t)o * C + c] = b;
+    }
+}
+
 __global__ void bn_frozen_kernel(const float* mm, const float* mv, int C, float eps, float* mean, float* rstd) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < C) { mean[c] = mm[c]; rstd[c] = 1.0f / sqrtf(mv[c] + eps); }
@@ -355,14 +371,23 @@ int64_t chunk_rows_for(int64_t rows, int64_t maxchunks, int64_t minrows) {
 extern "C" int bdetr_bn_bwd_chunks(int64_t rows) { return (int)cdiv64(rows, chunk_rows_for(rows, 512, 64)); }
 extern "C" int bdetr_ln_bwd_chunks(int64_t rows) { return (int)cdiv64(rows, chunk_rows_for(rows, 512, 16)); }
 
+constexpr int BN_FOLD = 64;
+extern "C" int bdetr_bn_stats_fold_rows(void) { return BN_FOLD; }
+
 extern "C" int bdetr_bn_stats(const float* x, int64_t rows, int C, const float* part_sum, const float* part_sq,
                               int nparts, float eps, float momentum, int bessel,
-                              float* mean, float* rstd, float* moving_mean, float* moving_var, void* stream) {
+                              float* mean, float* rstd, float* moving_mean, float* moving_var, float* fold_ws, void* stream) {
     BDETR_CHECK_ARG(mean && rstd && rows > 0 && C > 0, "bdetr_bn_stats: bad arguments");
     BDETR_CHECK_ARG(part_sum != nullptr && part_sq != nullptr && nparts > 0,
                     "bdetr_bn_stats: partial sums required (use bdetr_colstats to produce them from x)");
     (void)x;
     hipStream_t st = (hipStream_t)stream;
+    if (nparts > 4 * BN_FOLD && fold_ws != nullptr) {
+        // many epilogue partials (one per 32/64 output rows): fold them to BN_FOLD rows with a wide grid first
+        float* fa = fold_ws; float* fb = fold_ws + (int64_t)BN_FOLD * C;
+        hipLaunchKernelGGL(fold_partials2_kernel, dim3((C + 31) / 32, BN_FOLD), dim3(256), 0, st, part_sum, part_sq, nparts, C, BN_FOLD, fa, fb);
+        part_sum = fa; part_sq = fb; nparts = BN_FOLD;
+    }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, part_sum, part_sq, nparts, rows, C, eps, momentum, bessel,
                        mean, rstd, moving_mean, moving_var);
     return bdetr_launch_status("bn_finalize");

@@ -54,6 +54,8 @@ class Variable:
         self.pad_in_channels = pad_in_channels      # conv1: 3 -> 4 input channels (zero weights)
         self.value: Optional[torch.Tensor] = None
         self.grad: Optional[torch.Tensor] = None
+        self.grad_buf: Optional[torch.Tensor] = None   # persistent slice of the optimizer's flat gradient buffer
+        self._grad_fresh = False                        # grad_buf already holds this step's gradient
 
     # layout conversion -----------------------------------------------------------------
     def _to_internal(self, a: np.ndarray) -> np.ndarray:
@@ -92,6 +94,27 @@ class Variable:
     @property
     def num_params(self) -> int:
         return int(np.prod(self.keras_shape))
+
+    @property
+    def needs_grad(self) -> bool:
+        return self.trainable and getattr(self, "owner", None) is not None and self.owner.trainable
+
+    def reset_grad(self) -> None:
+        self.grad, self._grad_fresh = None, False
+
+    def accumulate_grad(self, fn) -> None:
+        """``fn(out)`` writes this variable's gradient into ``out`` (or allocates when out is None)
+        and returns it.  The first contribution of a step lands directly in the optimizer's flat
+        buffer slice (no staging copy); later ones (shared layers) are added in place."""
+        if not self.needs_grad:
+            return
+        if self.grad is None and self.grad_buf is not None:
+            fn(self.grad_buf)
+            self.grad, self._grad_fresh = self.grad_buf, True
+        elif self.grad is None:
+            self.grad = fn(None)
+        else:
+            K.axpy_(1.0, fn(None).view(self.grad.shape), self.grad)
 
 
 # Keras initialisers (SURVEY S17) -- host-side numpy, seeded per variable name
@@ -164,7 +187,13 @@ class Tape:
                     continue
                 key = id(t)
                 if key in grads:
-                    grads[key] = K.add(grads[key], g.view(grads[key].shape))
+                    have = grads[key]
+                    if getattr(have, "_bdetr_owned", False):       # sole owner: accumulate in place
+                        K.axpy_(1.0, g.view(have.shape), have)
+                    else:
+                        s = K.add(have, g.view(have.shape))
+                        s._bdetr_owned = True
+                        grads[key] = s
                 else:
                     grads[key] = g
         return grads
@@ -275,7 +304,8 @@ class Layer:
 
     def __call__(self, inputs, training: bool = False, **kwargs):
         if not self.built:
-            shapes = [tuple(t.shape) for t in inputs] if isinstance(inputs, (list, tuple)) else inputs
+            shapes = [tuple(t.value.shape if isinstance(t, Variable) else t.shape) for t in inputs] \
+                if isinstance(inputs, (list, tuple)) else inputs
             self.build(shapes)
             self.built = True
         return self.call(inputs, training=training, **kwargs)

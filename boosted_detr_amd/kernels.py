@@ -203,9 +203,12 @@ def colstats(x2d):
 
 def bn_stats(rows, Cc, parts, eps, momentum, bessel, moving_mean, moving_var, like):
     psum, psq, n = parts
+    L = _lib.lib()
     mean, rstd = empty(Cc, like=like), empty(Cc, like=like)
-    check(_lib.lib().bdetr_bn_stats(None, rows, Cc, _p(psum), _p(psq), n, eps, momentum, int(bessel), _p(mean), _p(rstd),
-                                    _p(moving_mean), _p(moving_var), _stream()), "bn_stats")
+    fold = L.bdetr_bn_stats_fold_rows()
+    ws = empty(2 * fold * Cc, like=like) if n > 4 * fold else None
+    check(L.bdetr_bn_stats(None, rows, Cc, _p(psum), _p(psq), n, eps, momentum, int(bessel), _p(mean), _p(rstd),
+                           _p(moving_mean), _p(moving_var), _p(ws), _stream()), "bn_stats")
     return mean, rstd
 
 
@@ -227,12 +230,13 @@ def bn_apply(x2d, mean, rstd, gamma, beta, residual=None, relu=False, out=None):
     return out
 
 
-def bn_bwd(dout, out, x2d, mean, rstd, gamma, relu, frozen, want_residual_grad=False):
-    _chk(dout, out, x2d, mean, rstd, gamma)
+def bn_bwd(dout, out, x2d, mean, rstd, gamma, relu, frozen, want_residual_grad=False, dgamma=None, dbeta=None):
+    _chk(dout, out, x2d, mean, rstd, gamma, dgamma, dbeta)
     L = _lib.lib()
     rows, Cc = x2d.shape
     dx = torch.empty_like(x2d)
-    dgamma, dbeta = empty(Cc, like=x2d), empty(Cc, like=x2d)
+    dgamma = empty(Cc, like=x2d) if dgamma is None else dgamma
+    dbeta = empty(Cc, like=x2d) if dbeta is None else dbeta
     dres = torch.empty_like(x2d) if want_residual_grad else None
     ws = empty(2 * Cc * L.bdetr_bn_bwd_chunks(rows), like=x2d)
     check(L.bdetr_bn_bwd(_p(dout), _p(out), _p(x2d), _p(mean), _p(rstd), _p(gamma), int(relu), int(frozen), _p(dx), _p(dgamma), _p(dbeta),
@@ -289,12 +293,13 @@ def add_dropout_layernorm_fwd(x2d, y2d, gamma, beta, eps, rate=0.0, seed=0):
     return out, mean, rstd
 
 
-def add_dropout_layernorm_bwd(dout, x2d, y2d, gamma, mean, rstd, rate=0.0, seed=0):
-    _chk(dout, x2d, y2d, gamma, mean, rstd)
+def add_dropout_layernorm_bwd(dout, x2d, y2d, gamma, mean, rstd, rate=0.0, seed=0, dgamma=None, dbeta=None):
+    _chk(dout, x2d, y2d, gamma, mean, rstd, dgamma, dbeta)
     L = _lib.lib()
     rows, D = x2d.shape
     dx, dy = torch.empty_like(x2d), torch.empty_like(x2d)
-    dgamma, dbeta = empty(D, like=x2d), empty(D, like=x2d)
+    dgamma = empty(D, like=x2d) if dgamma is None else dgamma
+    dbeta = empty(D, like=x2d) if dbeta is None else dbeta
     ws = empty(2 * D * L.bdetr_ln_bwd_chunks(rows), like=x2d)
     check(L.bdetr_add_dropout_layernorm_bwd(_p(dout), _p(x2d), _p(y2d), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dy), _p(dgamma), _p(dbeta),
                                             _p(ws), rows, D, rate, seed, 0, _stream()), "add_dropout_layernorm_bwd")
@@ -347,9 +352,10 @@ def add_bcast_rows(a, row):
     return out
 
 
-def sum_over_batch(x, n):
-    _chk(x)
-    out = empty(n, like=x)
+def sum_over_batch(x, n, out=None):
+    _chk(x, out)
+    if out is None:
+        out = empty(n, like=x)
     check(_lib.lib().bdetr_sum_over_batch(_p(x), _p(out), x.numel() // n, n, 0, _stream()), "sum_over_batch")
     return out
 

@@ -1,6 +1,10 @@
 """Tape-recorded composite ops of the hot path.  Each function runs HIP kernels for the
 forward and, when a Tape is recording, registers the closure that runs the backward kernels.
 
+Activation gradients travel through the Tape; PARAMETER gradients do not: each backward
+closure writes them straight into the variable's slice of the optimizer's flat gradient buffer
+(``GradSink``), so there is no per-tensor staging copy before the all-reduce / optimizer.
+
 Tensors are NHWC / [B,T,D]; ops view them as 2-D row matrices internally.
 """
 from __future__ import annotations
@@ -37,6 +41,41 @@ def _2d(t: torch.Tensor) -> torch.Tensor:
     return t.view(-1, t.shape[-1])
 
 
+def _own(t: torch.Tensor) -> torch.Tensor:
+    """Mark a freshly produced gradient tensor as solely owned by the Tape (safe to accumulate into)."""
+    t._bdetr_owned = True
+    return t
+
+
+class GradSink:
+    """Where a backward kernel writes one parameter's gradient.
+
+    direct: first contribution of the step and the optimizer has a flat buffer -> write in place.
+    temp  : later contribution (shared layer) or no optimizer yet -> temporary, added on commit.
+    drop  : the variable is frozen but the kernel always produces the value -> scratch."""
+
+    __slots__ = ("var", "buf", "mode")
+
+    def __init__(self, var: Variable):
+        self.var = var
+        if not var.needs_grad:
+            self.mode, self.buf = "drop", torch.empty_like(var.value)
+        elif var.grad is None and var.grad_buf is not None:
+            self.mode, self.buf = "direct", var.grad_buf
+        else:
+            self.mode, self.buf = "temp", torch.empty_like(var.value)
+
+    def commit(self) -> None:
+        v = self.var
+        if self.mode == "direct":
+            v.grad, v._grad_fresh = v.grad_buf, True
+        elif self.mode == "temp":
+            if v.grad is None:
+                v.grad = self.buf
+            else:
+                K.axpy_(1.0, self.buf.view(v.grad.shape), v.grad)
+
+
 # ----------------------------------------------------------------------------------------
 # backbone
 # ----------------------------------------------------------------------------------------
@@ -64,6 +103,15 @@ def _bn_forward(y2d, rows, Cc, parts, bn: BNState, use_batch_stats: bool, bessel
     return out, mean, rstd
 
 
+def _bn_backward(g2d, out2d, x2d, mean, rstd, bn: BNState, relu: bool, frozen: bool, want_residual_grad: bool):
+    sg, sb = GradSink(bn.gamma), GradSink(bn.beta)
+    dx, _, _, dres = K.bn_bwd(g2d, out2d, x2d, mean, rstd, bn.gamma.value, relu, frozen, want_residual_grad=want_residual_grad,
+                              dgamma=sg.buf, dbeta=sb.buf)
+    sg.commit()
+    sb.commit()
+    return dx, dres
+
+
 def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int, pad: int, relu: bool,
             residual: Optional[torch.Tensor] = None, training: bool = False, bn_batch_stats: Optional[bool] = None,
             x_needs_grad: bool = True) -> torch.Tensor:
@@ -79,16 +127,26 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
     out = out2d.view(N, g.OH, g.OW, Kout)
 
     def backward(g_out):
-        dy, dgamma, dbeta, dres = K.bn_bwd(_2d(g_out.contiguous()), out2d, y2d, mean, rstd, bn.gamma.value, relu, not use_batch,
-                                           want_residual_grad=residual is not None)
+        dy, dres = _bn_backward(_2d(g_out.contiguous()), out2d, y2d, mean, rstd, bn, relu, not use_batch, residual is not None)
         dy4 = dy.view(N, g.OH, g.OW, Kout)
-        dw = K.conv2d_bwd_weight(x, dy4, g)
-        db = K.colsum(dy)
-        dx = K.conv2d_bwd_data(dy4, w.value, g) if x_needs_grad else None
-        dr = dres.view(residual.shape) if residual is not None else None
-        return dx, dr, dw, db, dgamma, dbeta
+        if w.needs_grad:
+            s = GradSink(w)
+            K.conv2d_bwd_weight(x, dy4, g, dw=s.buf)
+            s.commit()
+        if b.needs_grad:
+            s = GradSink(b)
+            if use_batch:
+                # A bias in front of a batch-statistics BN has an exactly zero gradient: sum_rows(dy) =
+                # -rstd*gamma*mean(g*xhat)*sum(xhat) and sum(xhat) == 0.  (The fp64 oracle gives ~1e-15.)
+                K.zero_(s.buf)
+            else:
+                K.colsum(dy, out=s.buf)
+            s.commit()
+        dx = _own(K.conv2d_bwd_data(dy4, w.value, g)) if x_needs_grad else None
+        dr = _own(dres.view(residual.shape)) if residual is not None else None
+        return dx, dr
 
-    _rec([out], [x, residual, w.value, b.value, bn.gamma.value, bn.beta.value], backward)
+    _rec([out], [x, residual], backward)
     return out
 
 
@@ -107,12 +165,17 @@ def conv_act(x: torch.Tensor, w: Variable, b: Variable, stride: int, pad: int, a
             dpre = K.relu_bwd(y, g_out)
         else:
             dpre = g_out
-        dw = K.conv2d_bwd_weight(x, dpre, g)
-        db = K.colsum(_2d(dpre))
-        dx = K.conv2d_bwd_data(dpre, w.value, g)
-        return dx, dw, db
+        if w.needs_grad:
+            s = GradSink(w)
+            K.conv2d_bwd_weight(x, dpre, g, dw=s.buf)
+            s.commit()
+        if b.needs_grad:
+            s = GradSink(b)
+            K.colsum(_2d(dpre), out=s.buf)
+            s.commit()
+        return (_own(K.conv2d_bwd_data(dpre, w.value, g)),)
 
-    _rec([y], [x, w.value, b.value], backward)
+    _rec([y], [x], backward)
     return y
 
 
@@ -125,16 +188,16 @@ def batchnorm(x: torch.Tensor, bn: BNState, training: bool, bessel: bool) -> tor
     out = out2d.view(x.shape)
 
     def backward(g_out):
-        dx, dgamma, dbeta, _ = K.bn_bwd(_2d(g_out.contiguous()), None, x2d, mean, rstd, bn.gamma.value, False, not training)
-        return dx.view(x.shape), dgamma, dbeta
+        dx, _ = _bn_backward(_2d(g_out.contiguous()), None, x2d, mean, rstd, bn, False, not training, False)
+        return (_own(dx.view(x.shape)),)
 
-    _rec([out], [x, bn.gamma.value, bn.beta.value], backward)
+    _rec([out], [x], backward)
     return out
 
 
 def maxpool(x: torch.Tensor) -> torch.Tensor:
     y = K.maxpool_fwd(x)
-    _rec([y], [x], lambda g: (K.maxpool_bwd(x, y, g.contiguous()),))
+    _rec([y], [x], lambda g: (_own(K.maxpool_bwd(x, y, g.contiguous())),))
     return y
 
 
@@ -153,42 +216,80 @@ def dense(x: torch.Tensor, w: Variable, b: Variable, act: int = K.ACT_NONE) -> t
             g2d = K.relu_bwd(y2d, g2d)
         elif act == K.ACT_TANH:
             g2d = K.tanh_bwd(y2d, g2d)
-        dx = K.linear_bwd_data(g2d, w.value).view(x.shape)
-        dw = K.linear_bwd_weight(g2d, x2d)
-        db = K.colsum(g2d)
-        return dx, dw, db
+        if w.needs_grad:
+            s = GradSink(w)
+            K.linear_bwd_weight(g2d, x2d, dw=s.buf)
+            s.commit()
+        if b.needs_grad:
+            s = GradSink(b)
+            K.colsum(g2d, out=s.buf)
+            s.commit()
+        return (_own(K.linear_bwd_data(g2d, w.value).view(x.shape)),)
 
-    _rec([y], [x, w.value, b.value], backward)
+    _rec([y], [x], backward)
     return y
 
 
 def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     out = K.add(a, b)
-    _rec([out], [a, b], lambda g: (g, g))
+    _rec([out], [a, b], lambda g: (g, g))        # shared tensor: NOT owned
     return out
 
 
-def add_bcast(x: torch.Tensor, row: torch.Tensor) -> torch.Tensor:
-    """x [B, ...] + row [...]  (positional encoding tiled over the batch, transformers.py:299-300)."""
-    out = K.add_bcast_rows(x, row)
-    n = row.numel()
-    _rec([out], [x, row], lambda g: (g, K.sum_over_batch(g.contiguous(), n).view(row.shape)))
+def _param_or_tensor_grad(p, fn):
+    """Gradient of a broadcast operand that may be a Variable's value (positional table, queries)."""
+    if isinstance(p, Variable):
+        if p.needs_grad:
+            s = GradSink(p)
+            fn(s.buf)
+            s.commit()
+        return None
+    return fn(None)
+
+
+def add_bcast(x: torch.Tensor, row) -> torch.Tensor:
+    """x [B, ...] + row [...]  (positional encoding tiled over the batch, transformers.py:299-300).
+    ``row`` is a tensor or a Variable."""
+    rv = row.value if isinstance(row, Variable) else row
+    out = K.add_bcast_rows(x, rv)
+    n = rv.numel()
+
+    def backward(g):
+        g = g.contiguous()
+        grow = _param_or_tensor_grad(row, lambda out_: K.sum_over_batch(g, n, out=out_))
+        return g, (grow.view(rv.shape) if grow is not None else None)
+
+    _rec([out], [x, None if isinstance(row, Variable) else row], backward)
     return out
 
 
-def tile_batch(row: torch.Tensor, B: int) -> torch.Tensor:
+def tile_batch(row: Variable, B: int) -> torch.Tensor:
     """row [...] -> [B, ...]  (DecoderPrep's tiled queries, transformers.py:445-447)."""
-    zeros = torch.empty((B,) + tuple(row.shape), dtype=row.dtype, device=row.device)
+    rv = row.value
+    zeros = torch.empty((B,) + tuple(rv.shape), dtype=rv.dtype, device=rv.device)
     K.zero_(zeros)
-    out = K.add_bcast_rows(zeros, row)
-    n = row.numel()
-    _rec([out], [row], lambda g: (K.sum_over_batch(g.contiguous(), n).view(row.shape),))
+    out = K.add_bcast_rows(zeros, rv)
+    n = rv.numel()
+
+    def backward(g):
+        g = g.contiguous()
+        _param_or_tensor_grad(row, lambda out_: K.sum_over_batch(g, n, out=out_))
+        return ()
+
+    _rec([out], [], backward)
     return out
 
 
 def reshape(x: torch.Tensor, shape) -> torch.Tensor:
     y = x.view(shape)
-    _rec([y], [x], lambda g: (g.contiguous().view(x.shape),))
+
+    def backward(g):
+        r = g.contiguous().view(x.shape)
+        if getattr(g, "_bdetr_owned", False):
+            r._bdetr_owned = True
+        return (r,)
+
+    _rec([y], [x], backward)
     return y
 
 
@@ -223,7 +324,7 @@ def attention_core(Q: torch.Tensor, Kt: torch.Tensor, V: torch.Tensor, heads: in
         K.gemm_raw(q, d, kk, dS, kk, True, Kt, D, False, dQ, D, nb0=B, nb1=heads, sa=sP, sb=(kk * D, d), sc=(q * D, d))
         dK = K.empty(B, kk, D, like=Q)
         K.gemm_raw(kk, d, q, dS, kk, False, Q, D, False, dK, D, nb0=B, nb1=heads, sa=sP, sb=(q * D, d), sc=(kk * D, d))
-        return dQ, dK, dV
+        return _own(dQ), _own(dK), _own(dV)
 
     _rec([O], [Q, Kt, V], backward)
     return O
@@ -239,10 +340,14 @@ def add_dropout_layernorm(x: torch.Tensor, y: torch.Tensor, gamma: Variable, bet
     out = out2d.view(x.shape)
 
     def backward(g_out):
-        dx, dy, dg, db = K.add_dropout_layernorm_bwd(_2d(g_out.contiguous()), x2d, y2d, gamma.value, mean, rstd, r, seed)
-        return dx.view(x.shape), dy.view(y.shape), dg, db
+        sg, sb = GradSink(gamma), GradSink(beta)
+        dx, dy, _, _ = K.add_dropout_layernorm_bwd(_2d(g_out.contiguous()), x2d, y2d, gamma.value, mean, rstd, r, seed,
+                                                   dgamma=sg.buf, dbeta=sb.buf)
+        sg.commit()
+        sb.commit()
+        return _own(dx.view(x.shape)), _own(dy.view(y.shape))
 
-    _rec([out], [x, y, gamma.value, beta.value], backward)
+    _rec([out], [x, y], backward)
     return out
 
 
@@ -251,18 +356,18 @@ def add_dropout_layernorm(x: torch.Tensor, y: torch.Tensor, gamma: Variable, bet
 # ----------------------------------------------------------------------------------------
 def softmax_lastdim(x: torch.Tensor) -> torch.Tensor:
     p = K.softmax_rows_fwd(_2d(x), 1.0).view(x.shape)
-    _rec([p], [x], lambda g: (K.softmax_rows_bwd(_2d(p), _2d(g.contiguous()), 1.0).view(x.shape),))
+    _rec([p], [x], lambda g: (_own(K.softmax_rows_bwd(_2d(p), _2d(g.contiguous()), 1.0).view(x.shape)),))
     return p
 
 
 def sigmoid(x: torch.Tensor) -> torch.Tensor:
     y = K.sigmoid_fwd(x)
-    _rec([y], [x], lambda g: (K.sigmoid_bwd(y, g.contiguous()),))
+    _rec([y], [x], lambda g: (_own(K.sigmoid_bwd(y, g.contiguous())),))
     return y
 
 
 def box_sigmoid(x: torch.Tensor) -> torch.Tensor:
     """3*sigmoid(x/100) - 1  (prediction_heads.py:44)."""
     y = K.boxsigmoid_fwd(x)
-    _rec([y], [x], lambda g: (K.boxsigmoid_bwd(y, g.contiguous()),))
+    _rec([y], [x], lambda g: (_own(K.boxsigmoid_bwd(y, g.contiguous())),))
     return y

@@ -98,6 +98,8 @@ class SGD:
         self.d_partial = torch.empty(self.nslabs, dtype=torch.float32, device=dev)
         self.d_norms = torch.empty(len(self.vars), dtype=torch.float32, device=dev)
         self.d_lr = torch.zeros(1, dtype=torch.float32, device=dev)
+        for v, gv in zip(self.vars, self.grad_views):
+            v.grad_buf = gv
         self._built_for = [id(v) for v in self.vars]
 
     def stage_gradients(self, variables: List[Variable]) -> None:
@@ -105,10 +107,12 @@ class SGD:
         if self._built_for != [id(v) for v in variables]:
             self.build(variables)
         for v, gv in zip(self.vars, self.grad_views):
+            if v.grad is gv:
+                continue                                 # the backward kernels wrote straight into the flat buffer
             if v.grad is None:
-                K.zero_(gv.view(-1)) if gv.is_contiguous() else gv.zero_()
+                gv.zero_()
             else:
-                gv.copy_(v.grad.view(gv.shape))          # D2D memcpy (plumbing)
+                gv.copy_(v.grad.view(gv.shape))          # D2D memcpy (plumbing): first step / shared-variable temporaries
             v.grad = gv
 
     def apply_gradients(self, grad_scale: float = 1.0) -> None:
@@ -241,12 +245,12 @@ class Model(Layer):
         """forward + matcher + loss + backward.  Leaves gradients in Variable.grad."""
         self._step_losses, self._loss_roots, self._step_metrics = [], [], {}
         ops.set_dropout_seed(0x5EED + self.steps_done)
+        for v in self.variables:
+            v.reset_grad()
         tape = Tape()
         with recording(tape):
             y_pred = self(data, training=True)
-        grads = tape.backward({id(t): t for t in self._loss_roots})
-        for v in self.variables:
-            v.grad = grads.get(id(v.value)) if v.trainable else None
+        tape.backward({id(t): t for t in self._loss_roots})     # parameter gradients land in Variable.grad (ops.GradSink)
         return y_pred
 
     def train_step(self, data: dict) -> Dict[str, torch.Tensor]:

@@ -172,12 +172,12 @@ class ImageEncoderAttention(Layer):
     def call(self, inputs, training=False):
         encoder_features = inputs[0]                       # [B,r,c,D]
         B, r, c, D = encoder_features.shape
-        pos = ops.reshape(self.positional_encoding.value, (r * c, D))
+        pos = self.positional_encoding            # Variable [r,c,D]; broadcast over the batch inside the add kernel
         x = ops.reshape(encoder_features, (B, r * c, D))
         for blk in self.EncoderBlocks:
             x = blk([x, pos], training=training)
         # the reference returns the batch-tiled positional tensor; the tile is kept implicit here
-        return ops.reshape(x, (B, r, c, D)), self.positional_encoding.value
+        return ops.reshape(x, (B, r, c, D)), self.positional_encoding
 
 
 class DecoderBlock_NoSelfAttention(Layer):
@@ -237,10 +237,10 @@ class DecoderPrep(Layer):
         self.init_decoder_features = self.add_weight("init_decoder_features", (self.num_object_preds, self.decoder_dim), "zeros")
 
     def call(self, inputs, training=False):
-        encoder_features, encoder_positional = inputs      # [B,r,c,D], [r,c,D]
+        encoder_features, encoder_positional = inputs      # [B,r,c,D], positional Variable [r,c,D]
         B, r, c, D = encoder_features.shape
         encoder_value = ops.reshape(encoder_features, (B, r * c, D))
-        encoder_key = ops.add_bcast(encoder_value, ops.reshape(encoder_positional, (r * c, D)))     # value + positional (441)
-        decoder_features = ops.tile_batch(self.init_decoder_features.value, B)
+        encoder_key = ops.add_bcast(encoder_value, encoder_positional)     # value + positional (441)
+        decoder_features = ops.tile_batch(self.init_decoder_features, B)
         decoder_positional = decoder_features
         return encoder_value, decoder_features, encoder_key, decoder_positional

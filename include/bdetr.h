@@ -38,6 +38,8 @@ int         bdetr_device_cus(void);
  * (2*I*J*R per GEMM) of everything launched since bdetr_prof_enable(1). */
 int bdetr_prof_enable(int on);
 int bdetr_prof_read(double* total_ms, int64_t* launches, double* flops);
+/* debug aid: one CSV row per recorded launch (shape, tile, loader kinds, ms, GFLOP) */
+int bdetr_prof_dump(const char* path);
 
 /* ---- activation codes for the GEMM / conv epilogue ---- */
 enum { BDETR_ACT_NONE = 0, BDETR_ACT_RELU = 1, BDETR_ACT_TANH = 2 };
@@ -115,7 +117,10 @@ int bdetr_colstats(const float* x, int64_t rows, int C, float* part_sum, float* 
  * (momentum; bessel!=0 uses the unbiased variance for the moving estimate).  x is unused. */
 int bdetr_bn_stats(const float* x, int64_t rows, int C, const float* part_sum, const float* part_sq,
                    int nparts, float eps, float momentum, int bessel,
-                   float* mean, float* rstd, float* moving_mean, float* moving_var, void* stream);
+                   float* mean, float* rstd, float* moving_mean, float* moving_var, float* fold_ws, void* stream);
+/* fold_ws (optional): 2*C*bdetr_bn_stats_fold_rows() floats; lets bn_stats pre-reduce thousands of
+ * epilogue partial rows with a wide grid before the fp64 finalise */
+int bdetr_bn_stats_fold_rows(void);
 /* inference-mode statistics: mean = moving_mean, rstd = 1/sqrt(moving_var+eps) */
 int bdetr_bn_stats_frozen(const float* moving_mean, const float* moving_var, int C, float eps,
                           float* mean, float* rstd, void* stream);
