@@ -48,6 +48,9 @@ def make_batch(B, H, W, M, C, seed):
     for b in range(B):
         n = int(num_objects[b])
         category[b, :n] = rng.integers(2, C, size=n)
+        k = rng.integers(0, 4, size=n)                      # <=3 attribute ids per object (COCO: A=3, weight 0)
+        for m in range(n):
+            attribute[b, m, :k[m]] = rng.integers(2, 3, size=k[m])
         bbox[b, :n, 0:2] = rng.uniform(0.0, 0.6, size=(n, 2))
         bbox[b, :n, 2:4] = rng.uniform(0.05, 0.4, size=(n, 2))
     return {"image": image, "category": category, "attribute": attribute, "bbox": bbox, "num_objects": num_objects}

@@ -173,3 +173,27 @@ def test_inference_decode(config1):
     want = np.array([[vocab[i] for i in row] for row in ids.numpy()])
     assert np.array_equal(category[..., 0], want)
     assert rel_err(boxes.cpu().numpy(), ref.box_preds.detach().numpy()) < 1e-3
+
+
+def test_against_committed_golden(config1):
+    """The HIP path against tests/golden/config1.npz (fp64 oracle vectors committed with the repo):
+    integer results bit-exact, floats within 1e-3 relative."""
+    import os
+    cfg, batch, model, y_pred, out, grads, params = config1
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config1.npz"))
+    model.set_weights_dict(params)
+    y = model.forward_backward(batch)
+    cat, att, box = [t.cpu().numpy() for t in y]
+    t = "config1/f64"
+    assert rel_err(cat, gold[f"{t}/cat_preds"]) < 1e-3
+    assert rel_err(box, gold[f"{t}/box_preds"]) < 1e-3
+    assert rel_err(att[:, :, ::16], gold[f"{t}/attribute_preds_slice"]) < 1e-3
+    assert np.array_equal(cat.argmax(-1), gold[f"{t}/class_ids"])
+    assert np.array_equal(model.loss_fn.last_match.cpu().numpy().astype(np.int64), gold[f"{t}/match"])
+    logs = model.logs_to_host(model.step_logs())
+    assert abs(logs["loss"] - gold[f"{t}/loss_vector"].mean()) <= 1e-3 * abs(gold[f"{t}/loss_vector"].mean())
+    for v in model.variables:
+        key = f"{t}/grad_norm/{v.name}"
+        if key in gold and v.trainable:
+            got = np.linalg.norm(v.grad_numpy().astype(np.float64))
+            assert abs(got - float(gold[key])) <= 2e-2 * float(gold[key]), (v.name, got, float(gold[key]))
