@@ -30,71 +30,85 @@ struct DenseOp { const float* p; int64_t ld, s0, s1; int rows, cols; };
 struct PatchOp { const float* p; int N, H, W, C, OH, OW, R, S, stride, pad; int rows, cols; };
 struct WFlipOp { const float* p; int K, C, R, S; int rows, cols; };
 
+// All HBM reads go through raw buffer loads with a branch-free "invalid -> out-of-range offset"
+// select: the hardware range check returns zeros for padding pixels, ragged tile edges and split-K
+// tails, so the staging loads carry no control flow and stay in flight under the MFMA block (with
+// branchy zero-fill code hipcc placed s_waitcnt vmcnt(0) in FRONT of the MFMAs).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0xFFFFFFF0u;              // byte offset beyond num_records -> load returns 0
+constexpr unsigned NUM_RECORDS = 0xFFFFFF00u;      // operands must span < 4 GB (checked on the host)
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    void* q = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(q, 0, (int)NUM_RECORDS, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
+}
+__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
+}
+
 template <int VEC>
 struct DenseLoader {
     using Op = DenseOp;
-    struct Ctx { const float* rowp; bool ok; };
+    struct Ctx { unsigned off; bool ok; };     // element offset of the row start
     static __device__ __forceinline__ const float* batch_base(const Op& op, int b0, int b1) {
         return op.p + (int64_t)b0 * op.s0 + (int64_t)b1 * op.s1;
     }
-    static __device__ __forceinline__ Ctx row_ctx(const Op& op, const float* base, int row) {
-        Ctx c; c.ok = row < op.rows; c.rowp = base + (int64_t)row * op.ld; return c;
+    static __device__ __forceinline__ Ctx row_ctx(const Op& op, int row, int row_limit) {
+        Ctx c; c.ok = row < row_limit; c.off = (unsigned)row * (unsigned)op.ld; return c;
     }
-    static __device__ __forceinline__ f32x4 load(const Op& op, const Ctx& c, int col) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    static __device__ __forceinline__ f32x4 load(__amdgpu_buffer_rsrc_t rs, const Op& op, const Ctx& c, int col, int col_limit) {
         if (VEC == 4) {
-            if (c.ok && col < op.cols) v = *reinterpret_cast<const f32x4*>(c.rowp + col);
+            return buf_load4(rs, (c.ok && col < col_limit) ? (c.off + (unsigned)col) * 4u : OOB);
         } else {
-            if (c.ok) {
+            f32x4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) if (col + e < op.cols) v[e] = c.rowp[col + e];
-            }
+            for (int e = 0; e < 4; ++e) v[e] = buf_load1(rs, (c.ok && col + e < col_limit) ? (c.off + (unsigned)(col + e)) * 4u : OOB);
+            return v;
         }
-        return v;
     }
 };
 
 struct PatchLoader {
     using Op = PatchOp;
-    struct Ctx { int64_t nbase; int ih0, iw0; bool ok; };
+    struct Ctx { int nbase; int ih0, iw0; bool ok; };
     static __device__ __forceinline__ const float* batch_base(const Op& op, int, int) { return op.p; }
-    static __device__ __forceinline__ Ctx row_ctx(const Op& op, const float*, int row) {
-        Ctx c; c.ok = row < op.rows;
+    static __device__ __forceinline__ Ctx row_ctx(const Op& op, int row, int row_limit) {
+        Ctx c; c.ok = row < row_limit;
         int ohw = op.OH * op.OW;
         int n = row / ohw; int rem = row - n * ohw;
         int oh = rem / op.OW; int ow = rem - oh * op.OW;
-        c.nbase = (int64_t)n * op.H * op.W;
+        c.nbase = n * op.H * op.W;
         c.ih0 = oh * op.stride - op.pad; c.iw0 = ow * op.stride - op.pad;
         return c;
     }
-    static __device__ __forceinline__ f32x4 load(const Op& op, const Ctx& c, int col) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (c.ok && col < op.cols) {
-            int tap = col / op.C; int ch = col - tap * op.C;
-            int r = tap / op.S; int s = tap - r * op.S;
-            int ih = c.ih0 + r, iw = c.iw0 + s;
-            if ((unsigned)ih < (unsigned)op.H && (unsigned)iw < (unsigned)op.W)
-                v = *reinterpret_cast<const f32x4*>(op.p + ((c.nbase + (int64_t)ih * op.W + iw) * op.C + ch));
-        }
-        return v;
+    static __device__ __forceinline__ f32x4 load(__amdgpu_buffer_rsrc_t rs, const Op& op, const Ctx& c, int col, int col_limit) {
+        int tap = col / op.C; int ch = col - tap * op.C;
+        int r = tap / op.S; int s = tap - r * op.S;
+        int ih = c.ih0 + r, iw = c.iw0 + s;
+        const bool ok = c.ok && col < col_limit && (unsigned)ih < (unsigned)op.H && (unsigned)iw < (unsigned)op.W;
+        const unsigned off = ((unsigned)(c.nbase + ih * op.W + iw) * (unsigned)op.C + (unsigned)ch) * 4u;
+        return buf_load4(rs, ok ? off : OOB);
     }
 };
 
 struct WFlipLoader {
     using Op = WFlipOp;
-    struct Ctx { const float* rowp; bool ok; };
+    struct Ctx { unsigned off; bool ok; };
     static __device__ __forceinline__ const float* batch_base(const Op& op, int, int) { return op.p; }
-    static __device__ __forceinline__ Ctx row_ctx(const Op& op, const float*, int row) {
-        Ctx c; c.ok = row < op.rows;
+    static __device__ __forceinline__ Ctx row_ctx(const Op& op, int row, int row_limit) {
+        Ctx c; c.ok = row < row_limit;
         int tap = row / op.K; int k = row - tap * op.K;
         int r = tap / op.S; int s = tap - r * op.S;
-        c.rowp = op.p + (((int64_t)k * op.R + (op.R - 1 - r)) * op.S + (op.S - 1 - s)) * op.C;
+        c.off = (unsigned)(((k * op.R + (op.R - 1 - r)) * op.S + (op.S - 1 - s)) * op.C);
         return c;
     }
-    static __device__ __forceinline__ f32x4 load(const Op& op, const Ctx& c, int col) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (c.ok && col < op.cols) v = *reinterpret_cast<const f32x4*>(c.rowp + col);
-        return v;
+    static __device__ __forceinline__ f32x4 load(__amdgpu_buffer_rsrc_t rs, const Op& op, const Ctx& c, int col, int col_limit) {
+        return buf_load4(rs, (c.ok && col < col_limit) ? (c.off + (unsigned)col) * 4u : OOB);
     }
 };
 
@@ -170,8 +184,11 @@ void igemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
     } else {
         b0 = blockIdx.z / g.nb1; b1 = blockIdx.z - b0 * g.nb1;
     }
-    const float* baseA = LA::batch_base(opa, b0, b1);
-    const float* baseB = LB::batch_base(opb, b0, b1);
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(LA::batch_base(opa, b0, b1));
+    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(LB::batch_base(opb, b0, b1));
+    // natural-matrix limits: r-contiguous operands have rows = x (I or J) and cols = r; x-contiguous the reverse
+    const int a_rows = A_RC ? opa.rows : min(opa.rows, r_end), a_cols = A_RC ? min(opa.cols, r_end) : opa.cols;
+    const int b_rows = B_RC ? opb.rows : min(opb.rows, r_end), b_cols = B_RC ? min(opb.cols, r_end) : opb.cols;
 
     // per-thread staging geometry
     typename LA::Ctx ctxA[GA::NV];
@@ -182,43 +199,27 @@ void igemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
         int v = tid + NTHREADS * p;
         int rt = v / GA::VPR, c4 = v - rt * GA::VPR;
         rowA[p] = rt; colA[p] = 4 * c4; ldsoffA[p] = rt * GA::LDS_LD + 4 * c4;
-        if (A_RC) ctxA[p] = LA::row_ctx(opa, baseA, i0 + rt);
+        if (A_RC) ctxA[p] = LA::row_ctx(opa, i0 + rt, a_rows);
     }
 #pragma unroll
     for (int p = 0; p < GB::NV; ++p) {
         int v = tid + NTHREADS * p;
         int rt = v / GB::VPR, c4 = v - rt * GB::VPR;
         rowB[p] = rt; colB[p] = 4 * c4; ldsoffB[p] = rt * GB::LDS_LD + 4 * c4;
-        if (B_RC) ctxB[p] = LB::row_ctx(opb, baseB, j0 + rt);
+        if (B_RC) ctxB[p] = LB::row_ctx(opb, j0 + rt, b_rows);
     }
 
     f32x4 stA[GA::NV], stB[GB::NV];
     auto load_stage = [&](int r0) {
 #pragma unroll
         for (int p = 0; p < GA::NV; ++p) {
-            if (A_RC) {
-                int col = r0 + colA[p];
-                f32x4 v = LA::load(opa, ctxA[p], col);
-                if (col >= r_end) v = f32x4{0.f, 0.f, 0.f, 0.f};     // split-K tail (r_end multiple of 4 or == R)
-                stA[p] = v;
-            } else {
-                int row = r0 + rowA[p];
-                typename LA::Ctx c = LA::row_ctx(opa, baseA, row < r_end ? row : 0x7fffffff);
-                stA[p] = LA::load(opa, c, i0 + colA[p]);
-            }
+            if (A_RC) stA[p] = LA::load(rsA, opa, ctxA[p], r0 + colA[p], a_cols);
+            else      stA[p] = LA::load(rsA, opa, LA::row_ctx(opa, r0 + rowA[p], a_rows), i0 + colA[p], a_cols);
         }
 #pragma unroll
         for (int p = 0; p < GB::NV; ++p) {
-            if (B_RC) {
-                int col = r0 + colB[p];
-                f32x4 v = LB::load(opb, ctxB[p], col);
-                if (col >= r_end) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                stB[p] = v;
-            } else {
-                int row = r0 + rowB[p];
-                typename LB::Ctx c = LB::row_ctx(opb, baseB, row < r_end ? row : 0x7fffffff);
-                stB[p] = LB::load(opb, c, j0 + colB[p]);
-            }
+            if (B_RC) stB[p] = LB::load(rsB, opb, ctxB[p], r0 + colB[p], b_cols);
+            else      stB[p] = LB::load(rsB, opb, LB::row_ctx(opb, r0 + rowB[p], b_rows), j0 + colB[p], b_cols);
         }
     };
     auto write_stage = [&](int buf) {
