@@ -66,7 +66,7 @@ SIGNATURES = {
     "bdetr_bn_stats_frozen": (I, [P, P, I, F, P, P, P]),
     "bdetr_bn_apply": (I, [P, P, P, P, P, P, I, P, L, I, P]),
     "bdetr_bn_bwd_chunks": (I, [L]),
-    "bdetr_bn_bwd": (I, [P, P, P, P, P, P, I, I, P, P, P, P, P, L, I, P]),
+    "bdetr_bn_bwd": (I, [P, P, P, P, P, P, P, I, I, P, P, P, P, P, L, I, P]),
     "bdetr_maxpool3x3s2_fwd": (I, [P, P, I, I, I, I, I, I, P]),
     "bdetr_maxpool3x3s2_bwd": (I, [P, P, P, P, I, I, I, I, I, I, P]),
     "bdetr_softmax_rows_fwd": (I, [P, P, L, I, F, P]),

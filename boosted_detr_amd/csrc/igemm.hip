@@ -14,6 +14,7 @@
 // (backbone.py:37-38,76-78; transformers.py:41-48,62-65,86,97,101,174-177;
 //  prediction_heads.py:40-43,106-110,175-179).
 #include "common.h"
+#include <stdlib.h>
 #include <utility>
 #include <vector>
 
@@ -342,14 +343,28 @@ int num_cus() {
 }
 
 // Pick the biggest tile that still gives every CU ~2 workgroups; small-J problems get narrow tiles.
+// BDETR_TILE=<bm>x<bn> (e.g. 128x64) forces a tile for tuning experiments.
 TileChoice choose_tile(int I, int J, int zdim) {
-    const int64_t want = 2LL * num_cus();
+    static int forced_bm = -1, forced_bn = -1;
+    if (forced_bm < 0) {
+        forced_bm = forced_bn = 0;
+        if (const char* e = getenv("BDETR_TILE")) sscanf(e, "%dx%d", &forced_bm, &forced_bn);
+    }
+    if (forced_bm > 0) {
+        if (J <= 32) return {128, 32};
+        return {forced_bm, forced_bn};
+    }
+    // Measured on MI355X (scratch/gemm_bench.py): the 64x64 tile (4 workgroups per CU, 16 MFMAs per
+    // wave between barriers) beats 128x128 / 128x64 on every shape of this model (M <= 409600,
+    // N <= 2048): 97-108 vs 51-95 TF/s; 128x128 only wins once there are >= ~16 tiles per CU.
     auto tiles = [&](int bm, int bn) { return cdiv64(I, bm) * cdiv64(J, bn) * zdim; };
     if (J <= 32) return {128, 32};
-    if (J <= 64) return tiles(128, 64) >= want ? TileChoice{128, 64} : TileChoice{64, 64};
-    if (tiles(128, 128) >= want) return {128, 128};
+    if (tiles(128, 128) >= 16LL * num_cus() && J >= 1024) return {128, 128};
     return {64, 64};
 }
+
+template <int BM, int BN, int WM, int WN, class LA, bool A_RC, class LB, bool B_RC>
+int launch_cfg(const typename LA::Op& a, const typename LB::Op& b, GemmParams g, int zdim, hipStream_t st);
 
 // ---- optional live profiling of the MFMA kernel family (bench.py's roofline leg) -----------------
 // When enabled, every igemm launch is bracketed by two hipEvents recorded on the launch stream; the

@@ -119,18 +119,29 @@ struct StatFn {
     }
 };
 
+// the BN affine map, written once with an explicit fma so that the forward (bn_apply) and the
+// backward's recomputed ReLU mask round identically
+__device__ __forceinline__ float bn_affine(float v, float m, float rs, float g, float b) { return __builtin_fmaf(v - m, rs * g, b); }
+
 struct BnBwdFn {   // a = g (masked dout), b = g * xhat
-    const float* dout; const float* out; const float* x; const float* mean; const float* rstd; int C; int relu;
+    const float* dout; const float* out; const float* x; const float* mean; const float* rstd; const float* gamma; const float* beta;
+    int C; int relu;
     __device__ __forceinline__ void operator()(int64_t r, int c, f32x4& a, f32x4& b) const {
         f32x4 g = *reinterpret_cast<const f32x4*>(dout + r * C + c);
-        if (relu) {
-            f32x4 o = *reinterpret_cast<const f32x4*>(out + r * C + c);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) if (!(o[e] > 0.f)) g[e] = 0.f;
-        }
         f32x4 xv = *reinterpret_cast<const f32x4*>(x + r * C + c);
         f32x4 m = *reinterpret_cast<const f32x4*>(mean + c);
         f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + c);
+        if (relu) {
+            if (out != nullptr) {
+                f32x4 o = *reinterpret_cast<const f32x4*>(out + r * C + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (!(o[e] > 0.f)) g[e] = 0.f;
+            } else {     // no residual: the mask is a function of x alone - recompute it, do not re-read `out`
+                f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c), bt = *reinterpret_cast<const f32x4*>(beta + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (!(bn_affine(xv[e], m[e], rs[e], gm[e], bt[e]) > 0.f)) g[e] = 0.f;
+            }
+        }
         a = g; b = g * ((xv - m) * rs);
     }
 };
@@ -144,7 +155,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
         f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
         f32x4 m = *reinterpret_cast<const f32x4*>(mean + c), rs = *reinterpret_cast<const f32x4*>(rstd + c);
         f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c), b = *reinterpret_cast<const f32x4*>(beta + c);
-        f32x4 o = (v - m) * (rs * g) + b;
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = bn_affine(v[e], m[e], rs[e], g[e], b[e]);
         if (residual != nullptr) o += reinterpret_cast<const f32x4*>(residual)[i];
         if (relu) {
 #pragma unroll
@@ -156,24 +169,33 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ out, const float* __restrict__ x,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta,
                                                            const float* __restrict__ dgamma, const float* __restrict__ dbeta, int relu, int frozen,
                                                            float* __restrict__ dx, float* __restrict__ dres, int64_t n4, int c4n, float inv_rows) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % c4n) * 4;
         f32x4 g = reinterpret_cast<const f32x4*>(dout)[i];
+        f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + c), gm = *reinterpret_cast<const f32x4*>(gamma + c);
+        f32x4 m = *reinterpret_cast<const f32x4*>(mean + c);
+        f32x4 xv = {0.f, 0.f, 0.f, 0.f};
+        const bool recompute = relu && out == nullptr;
+        if (!frozen || recompute) xv = reinterpret_cast<const f32x4*>(x)[i];
         if (relu) {
-            f32x4 o = reinterpret_cast<const f32x4*>(out)[i];
+            if (!recompute) {
+                f32x4 o = reinterpret_cast<const f32x4*>(out)[i];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) if (!(o[e] > 0.f)) g[e] = 0.f;
+                for (int e = 0; e < 4; ++e) if (!(o[e] > 0.f)) g[e] = 0.f;
+            } else {
+                f32x4 bt = *reinterpret_cast<const f32x4*>(beta + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (!(bn_affine(xv[e], m[e], rs[e], gm[e], bt[e]) > 0.f)) g[e] = 0.f;
+            }
         }
         if (dres != nullptr) reinterpret_cast<f32x4*>(dres)[i] = g;
-        f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + c), gm = *reinterpret_cast<const f32x4*>(gamma + c);
         f32x4 r;
         if (frozen) {
             r = g * (rs * gm);
         } else {
-            f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
-            f32x4 m = *reinterpret_cast<const f32x4*>(mean + c);
             f32x4 dg = *reinterpret_cast<const f32x4*>(dgamma + c), db = *reinterpret_cast<const f32x4*>(dbeta + c);
             f32x4 xh = (xv - m) * rs;
             r = (g - db * inv_rows - xh * (dg * inv_rows)) * (rs * gm);
@@ -421,22 +443,22 @@ extern "C" int bdetr_bn_apply(const float* x, const float* mean, const float* rs
 }
 
 extern "C" int bdetr_bn_bwd(const float* dout, const float* out, const float* x, const float* mean,
-                            const float* rstd, const float* gamma, int relu, int frozen,
+                            const float* rstd, const float* gamma, const float* beta, int relu, int frozen,
                             float* dx, float* dgamma, float* dbeta, float* dresidual,
                             float* ws, int64_t rows, int C, void* stream) {
     BDETR_CHECK_ARG(dout && x && mean && rstd && gamma && dx && dgamma && dbeta && ws && rows > 0 && C > 0 && C % 4 == 0,
                     "bdetr_bn_bwd: bad arguments (C %% 4 == 0 required)");
-    BDETR_CHECK_ARG(!relu || out, "bdetr_bn_bwd: relu needs the forward output");
+    BDETR_CHECK_ARG(!relu || out || beta, "bdetr_bn_bwd: relu needs the forward output, or beta to recompute the mask from x");
     hipStream_t st = (hipStream_t)stream;
     ColGeom g = col_geom(C);
     int64_t rpc = chunk_rows_for(rows, 512, 64);
     int nch = (int)cdiv64(rows, rpc);
     float* pa = ws; float* pb = ws + (int64_t)nch * C;
-    BnBwdFn f{dout, out, x, mean, rstd, C, relu};
+    BnBwdFn f{dout, out, x, mean, rstd, gamma, beta, C, relu};
     hipLaunchKernelGGL((colreduce2_kernel<BnBwdFn>), dim3(g.gx, nch), dim3(256), 0, st, f, rows, C, g.tx, rpc, pa, pb);
     hipLaunchKernelGGL(sum_partials2_kernel, dim3((C + 31) / 32), dim3(256), 0, st, pa, pb, nch, C, dbeta, dgamma);
     int64_t n4 = rows * C / 4;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n4, 256, 2)), dim3(256), 0, st, dout, out, x, mean, rstd, gamma, dgamma, dbeta,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n4, 256, 2)), dim3(256), 0, st, dout, out, x, mean, rstd, gamma, beta, dgamma, dbeta,
                        relu, frozen, dx, dresidual, n4, C / 4, 1.0f / (float)rows);
     return bdetr_launch_status("bn_bwd");
 }

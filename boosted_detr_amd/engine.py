@@ -178,16 +178,28 @@ class Tape:
             gouts = [grads.pop(id(o), None) for o in outputs]
             if all(g is None for g in gouts):
                 continue
-            gins = fn(*gouts)
+            acc = None
+            if getattr(fn, "wants_acc", False):
+                # offer the op the gradient tensors already accumulated for its inputs (only when the
+                # Tape is their sole owner) so it can add into them inside its own kernel epilogue
+                acc = []
+                for t in inputs:
+                    have = grads.get(id(t)) if t is not None else None
+                    acc.append(have if getattr(have, "_bdetr_owned", False) else None)
+                gins = fn(*gouts, acc=acc)
+            else:
+                gins = fn(*gouts)
             if not isinstance(gins, (tuple, list)):
                 gins = (gins,)
             assert len(gins) == len(inputs), (len(gins), len(inputs))
-            for t, g in zip(inputs, gins):
+            for i, (t, g) in enumerate(zip(inputs, gins)):
                 if t is None or g is None:
                     continue
                 key = id(t)
                 if key in grads:
                     have = grads[key]
+                    if acc is not None and acc[i] is not None and g is acc[i]:
+                        continue                                    # the op already accumulated into the offered tensor
                     if getattr(have, "_bdetr_owned", False):       # sole owner: accumulate in place
                         K.axpy_(1.0, g.view(have.shape), have)
                     else:

@@ -230,7 +230,7 @@ def bn_apply(x2d, mean, rstd, gamma, beta, residual=None, relu=False, out=None):
     return out
 
 
-def bn_bwd(dout, out, x2d, mean, rstd, gamma, relu, frozen, want_residual_grad=False, dgamma=None, dbeta=None):
+def bn_bwd(dout, out, x2d, mean, rstd, gamma, relu, frozen, want_residual_grad=False, dgamma=None, dbeta=None, beta=None):
     _chk(dout, out, x2d, mean, rstd, gamma, dgamma, dbeta)
     L = _lib.lib()
     rows, Cc = x2d.shape
@@ -239,7 +239,7 @@ def bn_bwd(dout, out, x2d, mean, rstd, gamma, relu, frozen, want_residual_grad=F
     dbeta = empty(Cc, like=x2d) if dbeta is None else dbeta
     dres = torch.empty_like(x2d) if want_residual_grad else None
     ws = empty(2 * Cc * L.bdetr_bn_bwd_chunks(rows), like=x2d)
-    check(L.bdetr_bn_bwd(_p(dout), _p(out), _p(x2d), _p(mean), _p(rstd), _p(gamma), int(relu), int(frozen), _p(dx), _p(dgamma), _p(dbeta),
+    check(L.bdetr_bn_bwd(_p(dout), _p(out), _p(x2d), _p(mean), _p(rstd), _p(gamma), _p(beta), int(relu), int(frozen), _p(dx), _p(dgamma), _p(dbeta),
                          _p(dres), _p(ws), rows, Cc, _stream()), "bn_bwd")
     return dx, dgamma, dbeta, dres
 

@@ -105,8 +105,10 @@ def _bn_forward(y2d, rows, Cc, parts, bn: BNState, use_batch_stats: bool, bessel
 
 def _bn_backward(g2d, out2d, x2d, mean, rstd, bn: BNState, relu: bool, frozen: bool, want_residual_grad: bool):
     sg, sb = GradSink(bn.gamma), GradSink(bn.beta)
-    dx, _, _, dres = K.bn_bwd(g2d, out2d, x2d, mean, rstd, bn.gamma.value, relu, frozen, want_residual_grad=want_residual_grad,
-                              dgamma=sg.buf, dbeta=sb.buf)
+    # without a residual the ReLU mask is a function of x alone: the kernel recomputes it instead of reading `out`
+    mask_src = out2d if (relu and want_residual_grad) else None
+    dx, _, _, dres = K.bn_bwd(g2d, mask_src, x2d, mean, rstd, bn.gamma.value, relu, frozen, want_residual_grad=want_residual_grad,
+                              dgamma=sg.buf, dbeta=sb.buf, beta=bn.beta.value)
     sg.commit()
     sb.commit()
     return dx, dres
@@ -126,7 +128,7 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
     out2d, mean, rstd = _bn_forward(y2d, g.M, Kout, parts, bn, use_batch, True, res2d, relu)
     out = out2d.view(N, g.OH, g.OW, Kout)
 
-    def backward(g_out):
+    def backward(g_out, acc=None):
         dy, dres = _bn_backward(_2d(g_out.contiguous()), out2d, y2d, mean, rstd, bn, relu, not use_batch, residual is not None)
         dy4 = dy.view(N, g.OH, g.OW, Kout)
         if w.needs_grad:
@@ -142,10 +144,18 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
             else:
                 K.colsum(dy, out=s.buf)
             s.commit()
-        dx = _own(K.conv2d_bwd_data(dy4, w.value, g)) if x_needs_grad else None
+        dx = None
+        if x_needs_grad:
+            if acc is not None and acc[0] is not None:
+                # residual merge fused into the GEMM epilogue: dx += conv_transpose(dy) (no separate add pass)
+                dx = K.conv2d_bwd_data(dy4, w.value, g, dx=acc[0].view(N, H, W, Cin), accumulate=True)
+                dx = acc[0]
+            else:
+                dx = _own(K.conv2d_bwd_data(dy4, w.value, g))
         dr = _own(dres.view(residual.shape)) if residual is not None else None
         return dx, dr
 
+    backward.wants_acc = True
     _rec([out], [x, residual], backward)
     return out
 

@@ -129,13 +129,14 @@ int bdetr_bn_apply(const float* x, const float* mean, const float* rstd, const f
                    const float* beta, const float* residual, int relu, float* out,
                    int64_t rows, int C, void* stream);
 /* backward of bn_apply.  dout: gradient w.r.t. out; out: forward output (for the ReLU mask;
- * may be NULL when relu==0).  Produces dx, dgamma[C], dbeta[C] and, when dresidual!=NULL,
+ * may be NULL when relu==0, or when relu==1 and there was no residual: the mask is then recomputed
+ * from x with the forward's exact affine map, saving one full read of `out` per pass).  Produces dx, dgamma[C], dbeta[C] and, when dresidual!=NULL,
  * the masked gradient that flows to the residual branch (dresidual may alias dout).
  * frozen!=0: statistics were constants (inference-mode BN).  ws: 2*C*nchunks floats where
  * nchunks = bdetr_bn_bwd_chunks(rows). */
 int bdetr_bn_bwd_chunks(int64_t rows);
 int bdetr_bn_bwd(const float* dout, const float* out, const float* x, const float* mean,
-                 const float* rstd, const float* gamma, int relu, int frozen,
+                 const float* rstd, const float* gamma, const float* beta, int relu, int frozen,
                  float* dx, float* dgamma, float* dbeta, float* dresidual,
                  float* ws, int64_t rows, int C, void* stream);
 
