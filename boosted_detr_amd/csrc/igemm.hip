@@ -210,24 +210,26 @@ void igemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
         if (B_RC) ctxB[p] = LB::row_ctx(opb, j0 + rt, b_rows);
     }
 
-    f32x4 stA[GA::NV], stB[GB::NV];
-    auto load_stage = [&](int r0) {
+    // Two register staging sets: the loads of K-step t+2 are issued while K-step t computes, so an
+    // HBM round trip has two full K-steps (not one) of MFMA work to hide under.
+    f32x4 stA0[GA::NV], stB0[GB::NV], stA1[GA::NV], stB1[GB::NV];
+    auto load_stage = [&](int r0, f32x4 (&ra)[GA::NV], f32x4 (&rb)[GB::NV]) {
 #pragma unroll
         for (int p = 0; p < GA::NV; ++p) {
-            if (A_RC) stA[p] = LA::load(rsA, opa, ctxA[p], r0 + colA[p], a_cols);
-            else      stA[p] = LA::load(rsA, opa, LA::row_ctx(opa, r0 + rowA[p], a_rows), i0 + colA[p], a_cols);
+            if (A_RC) ra[p] = LA::load(rsA, opa, ctxA[p], r0 + colA[p], a_cols);
+            else      ra[p] = LA::load(rsA, opa, LA::row_ctx(opa, r0 + rowA[p], a_rows), i0 + colA[p], a_cols);
         }
 #pragma unroll
         for (int p = 0; p < GB::NV; ++p) {
-            if (B_RC) stB[p] = LB::load(rsB, opb, ctxB[p], r0 + colB[p], b_cols);
-            else      stB[p] = LB::load(rsB, opb, LB::row_ctx(opb, r0 + rowB[p], b_rows), j0 + colB[p], b_cols);
+            if (B_RC) rb[p] = LB::load(rsB, opb, ctxB[p], r0 + colB[p], b_cols);
+            else      rb[p] = LB::load(rsB, opb, LB::row_ctx(opb, r0 + rowB[p], b_rows), j0 + colB[p], b_cols);
         }
     };
-    auto write_stage = [&](int buf) {
+    auto write_stage = [&](int buf, const f32x4 (&ra)[GA::NV], const f32x4 (&rb)[GB::NV]) {
 #pragma unroll
-        for (int p = 0; p < GA::NV; ++p) *reinterpret_cast<f32x4*>(lds + buf * STAGE_FLOATS + ldsoffA[p]) = stA[p];
+        for (int p = 0; p < GA::NV; ++p) *reinterpret_cast<f32x4*>(lds + buf * STAGE_FLOATS + ldsoffA[p]) = ra[p];
 #pragma unroll
-        for (int p = 0; p < GB::NV; ++p) *reinterpret_cast<f32x4*>(lds + buf * STAGE_FLOATS + GA::LDS_FLOATS + ldsoffB[p]) = stB[p];
+        for (int p = 0; p < GB::NV; ++p) *reinterpret_cast<f32x4*>(lds + buf * STAGE_FLOATS + GA::LDS_FLOATS + ldsoffB[p]) = rb[p];
     };
 
     f32x16 acc[TM][TN];
@@ -238,17 +240,7 @@ void igemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-    const int nk = (r_end - r_begin + BK - 1) / BK;
-    if (nk > 0) {
-        load_stage(r_begin);
-        write_stage(0);
-    }
-    __syncthreads();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_stage(r_begin + (kt + 1) * BK);     // global loads in flight under the MFMAs
-
+    auto compute = [&](int buf) {
         const float* sA = lds + buf * STAGE_FLOATS;
         const float* sB = sA + GA::LDS_FLOATS;
 #pragma unroll
@@ -282,7 +274,27 @@ void igemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
                     for (int b = 0; b < TN; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][e], fb[b][e], acc[a][b], 0, 0, 0);
         }
-        if (kt + 1 < nk) write_stage(buf ^ 1);
+    };
+
+    const int nk = (r_end - r_begin + BK - 1) / BK;
+    if (nk > 0) {
+        load_stage(r_begin, stA0, stB0);
+        if (nk > 1) load_stage(r_begin + BK, stA1, stB1);
+        write_stage(0, stA0, stB0);
+    }
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; kt += 2) {
+        // even step: tile kt is in LDS buffer 0, tile kt+1 is in flight in set 1
+        if (kt + 2 < nk) load_stage(r_begin + (kt + 2) * BK, stA0, stB0);
+        compute(0);
+        if (kt + 1 < nk) write_stage(1, stA1, stB1);
+        __syncthreads();
+        if (kt + 1 >= nk) break;
+        // odd step: tile kt+1 is in LDS buffer 1, tile kt+2 is in flight in set 0
+        if (kt + 3 < nk) load_stage(r_begin + (kt + 3) * BK, stA1, stB1);
+        compute(1);
+        if (kt + 2 < nk) write_stage(0, stA0, stB0);
         __syncthreads();
     }
 
