@@ -126,6 +126,7 @@ struct GemmParams {
     float* c; int64_t ldc, sc0, sc1;
     const float* bias; float alpha; int act; int mode;
     float* stat_sum; float* stat_sq;    // [tiles_i*WM][J] partial column sums (may be null)
+    int vec_store;                      // C rows are 16-byte aligned and J % 4 == 0: LDS-transposed float4 stores
     int rowmap;                         // scatter C rows through a strided-pixel map (conv s>1 bwd-data)
     int rm_OW, rm_OHOW, rm_H, rm_W, rm_stride;
 };
@@ -300,6 +301,13 @@ void igemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
 
     // ---------------- epilogue ----------------
     float* cbase = g.c + (int64_t)b0 * g.sc0 + (int64_t)b1 * g.sc1;
+    auto out_row = [&](int i) -> int64_t {
+        if (!g.rowmap) return i;
+        int n = i / g.rm_OHOW; int rem = i - n * g.rm_OHOW;
+        int oh = rem / g.rm_OW; int ow = rem - oh * g.rm_OW;
+        return ((int64_t)n * g.rm_H + (int64_t)oh * g.rm_stride) * g.rm_W + (int64_t)ow * g.rm_stride;
+    };
+    // bias + activation in registers, BN partial statistics from registers
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
         const int j = j0 + wn * WTN + b * 32 + li;
@@ -311,20 +319,9 @@ void igemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int i = i0 + wm * WTM + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (i < g.I && jok) {
-                    float v = apply_act(g.alpha * acc[a][b][e] + bias, g.act);
-                    int64_t orow = i;
-                    if (g.rowmap) {
-                        int n = i / g.rm_OHOW; int rem = i - n * g.rm_OHOW;
-                        int oh = rem / g.rm_OW; int ow = rem - oh * g.rm_OW;
-                        orow = ((int64_t)n * g.rm_H + (int64_t)oh * g.rm_stride) * g.rm_W + (int64_t)ow * g.rm_stride;
-                    }
-                    float* dst = cbase + orow * g.ldc + j;
-                    if (g.mode == ST_STORE) *dst = v;
-                    else if (g.mode == ST_ACCUM) *dst += v;
-                    else atomicAdd(dst, v);
-                    csum += v; csq += v * v;
-                }
+                const float v = apply_act(g.alpha * acc[a][b][e] + bias, g.act);
+                acc[a][b][e] = v;
+                if (i < g.I && jok) { csum += v; csq += v * v; }
             }
         }
         if (g.stat_sum != nullptr) {
@@ -334,6 +331,54 @@ void igemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
                 const int64_t chunk = (int64_t)tile_i * WM + wm;
                 g.stat_sum[chunk * g.J + j] = csum;
                 g.stat_sq[chunk * g.J + j] = csq;
+            }
+        }
+    }
+
+    if (g.vec_store && g.mode != ST_ATOMIC) {
+        // Transpose the tile through LDS (the staging buffers are free after the last barrier) so that
+        // every lane stores 16 contiguous bytes: whole 256-byte (BN=64) rows per 16 lanes instead of
+        // 4-byte stores in 128-byte segments - 4x fewer store instructions, full-line writes.
+        constexpr int CLD = (BM * (BN + 4) <= 2 * STAGE_FLOATS) ? BN + 4 : BN;
+        static_assert(BM * CLD <= 2 * STAGE_FLOATS, "epilogue tile must fit in the staging LDS");
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    lds[(wm * WTM + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * CLD + wn * WTN + b * 32 + li] = acc[a][b][e];
+        __syncthreads();
+        constexpr int V_PER_ROW = BN / 4;
+#pragma unroll
+        for (int v = tid; v < BM * V_PER_ROW; v += NTHREADS) {
+            const int r = v / V_PER_ROW, c4 = v - r * V_PER_ROW;
+            const int i = i0 + r, j = j0 + 4 * c4;
+            if (i < g.I && j < g.J) {
+                f32x4 val = *reinterpret_cast<const f32x4*>(lds + r * CLD + 4 * c4);
+                f32x4* dst = reinterpret_cast<f32x4*>(cbase + out_row(i) * g.ldc + j);
+                if (g.mode == ST_ACCUM) val += *dst;
+                *dst = val;
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int j = j0 + wn * WTN + b * 32 + li;
+        if (j >= g.J) continue;
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int i = i0 + wm * WTM + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (i < g.I) {
+                    float* dst = cbase + out_row(i) * g.ldc + j;
+                    const float v = acc[a][b][e];
+                    if (g.mode == ST_STORE) *dst = v;
+                    else if (g.mode == ST_ACCUM) *dst += v;
+                    else atomicAdd(dst, v);
+                }
             }
         }
     }
@@ -409,6 +454,7 @@ int launch_cfg(const typename LA::Op& a, const typename LB::Op& b, GemmParams g,
     g.tiles_i = (int)cdiv64(g.I, BM);
     g.tiles_j = (int)cdiv64(g.J, BN);
     dim3 grid(g.tiles_i * g.tiles_j, 1, zdim);
+    g.vec_store = (g.J % 4 == 0) && (g.ldc % 4 == 0) && (g.sc0 % 4 == 0) && (g.sc1 % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.c) & 15) == 0);
     const bool prof = g_prof_on;
     if (prof) prof_begin(st, 2.0 * (double)g.I * (double)g.J * (double)g.R * (g.splitk > 1 ? 1.0 : (double)zdim), g.I, g.J, g.R, zdim, BM, BN,
                          LoaderId<LA>::v * 1000 + (A_RC ? 100 : 0) + LoaderId<LB>::v * 10 + (B_RC ? 1 : 0));
