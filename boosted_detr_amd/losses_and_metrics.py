@@ -84,6 +84,7 @@ class MatchingLoss(Layer):
         self.loss_scale = 1.0            # 1/num_replicas under data parallelism
         self.last_match: Optional[torch.Tensor] = None
         self.last_cost: Optional[torch.Tensor] = None
+        self.last_num_objects: Optional[torch.Tensor] = None
         self.built = True
 
     def call(self, inputs, training=False):
@@ -99,7 +100,7 @@ class MatchingLoss(Layer):
         tape = current_tape()
         losses, d_cat, d_att, d_box = K.set_loss(d, cat_preds, attribute_preds, box_preds, category, attribute, bbox,
                                                  num_objects, match, loss_scale=self.loss_scale, want_grads=tape is not None)
-        self.last_match, self.last_cost = match, cost
+        self.last_match, self.last_cost, self.last_num_objects = match, cost, num_objects
         if tape is not None:
             tape.record([losses], [cat_preds, attribute_preds, box_preds], lambda g: (d_cat, d_att, d_box))
         total, cat_l, att_l, box_l, exist_l, iou = (losses[i] for i in range(6))

@@ -213,6 +213,7 @@ class Model(Layer):
         self._step_metrics: Dict[str, torch.Tensor] = {}
         self._dp: Optional[DataParallel] = None
         self.steps_done = 0
+        self.validate_matching = False      # fit() turns this on: it synchronises every step anyway (host logging)
 
     # -- Keras bookkeeping -----------------------------------------------------------------
     def add_loss(self, loss) -> None:
@@ -257,6 +258,11 @@ class Model(Layer):
         if self.optimizer is None:
             raise RuntimeError("call compile(optimizer=...) before fit/train_step")
         self.forward_backward(data)
+        if self.validate_matching:
+            # scipy raises ValueError on NaN/-inf or infeasible cost matrices (the reference's
+            # tf.numpy_function then fails the step); the GPU solver leaves such rows at -1.
+            from .losses_and_metrics import MatchingAssignment
+            MatchingAssignment.validate(self.loss_fn.last_match, self.loss_fn.last_num_objects, self.num_object_preds)
         tv = self.trainable_variables
         self.optimizer.stage_gradients(tv)
         if self._dp is not None:
@@ -287,6 +293,7 @@ class Model(Layer):
             cb.set_model(self)
         history = {"loss": []}
         self.stop_training = False
+        self.validate_matching = True
         for epoch in range(epochs):
             t0, n, sums = time.time(), 0, {}
             for step, batch in enumerate(x):
