@@ -68,6 +68,17 @@ def build_model(args):
     return model
 
 
+def hbm_traffic_per_launch():
+    """HBM bytes per igemm launch from the PMC passes committed under profiles/ (rocprofv3 --pmc
+    FETCH_SIZE and --pmc WRITE_SIZE in separate runs of this same command, with the gfx950 corrections
+    of MI355X_MICROARCH.md: FETCH_SIZE x2, KB units).  None when the file is absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_igemm_hbm_traffic.json")) as f:
+            return round(json.load(f)["hbm_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def usable_cores() -> int:
     """CPU share of this process: affinity mask, capped by the cgroup quota and by 16 (the GPU box
     gives one GPU's job 16 cores; os.cpu_count() reports the whole host and oversubscribes)."""
@@ -192,7 +203,7 @@ def main():
         if ms.value > 0 and n.value > 0:
             ach = fl.value / (ms.value * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": hbm_traffic_per_launch(),
                     "kernel": "igemm_kernel (fp32 MFMA implicit-GEMM family: conv fwd/bwd-data/bwd-weight, dense, attention GEMMs)",
                     "launches_per_step": n.value // args.steps, "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
                     "avg_launch_gflop": round(fl.value / n.value / 1e9, 3),
