@@ -213,6 +213,61 @@ class Tape:
 
 _TAPE: Optional[Tape] = None
 
+# ----------------------------------------------------------------------------------------
+# side stream: weight-gradient GEMMs run off the critical path
+# ----------------------------------------------------------------------------------------
+# In the backward pass only the activation-gradient chain (BN-bwd -> bwd-data) is sequential; the
+# weight-gradient GEMMs are consumed by nobody until the optimizer runs.  They are launched on a
+# second HIP stream so that (a) their MFMA-bound workgroups fill the tails of the main stream's
+# kernels and (b) they overlap the HBM-bound BN/LayerNorm backward kernels of the earlier layers.
+_SIDE = {"stream": None, "enabled": True, "used": False}
+
+
+def side_stream() -> Optional["torch.cuda.Stream"]:
+    if not _SIDE["enabled"]:
+        return None
+    if _SIDE["stream"] is None:
+        _SIDE["stream"] = torch.cuda.Stream(device=device())
+    return _SIDE["stream"]
+
+
+def set_side_stream_enabled(on: bool) -> None:
+    _SIDE["enabled"] = bool(on)
+
+
+class on_side_stream:
+    """``with on_side_stream(t1, t2, ...)``: run the body on the side stream after everything already
+    queued on the current stream; the listed tensors are kept alive for the side stream."""
+
+    def __init__(self, *tensors):
+        self.tensors = [t for t in tensors if t is not None]
+        self.side = side_stream()
+
+    def __enter__(self):
+        if self.side is None:
+            return self
+        ev = torch.cuda.Event()
+        ev.record()
+        self.side.wait_event(ev)
+        for t in self.tensors:
+            t.record_stream(self.side)
+        self.ctx = torch.cuda.stream(self.side)
+        self.ctx.__enter__()
+        _SIDE["used"] = True
+        return self
+
+    def __exit__(self, *exc):
+        if self.side is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
+def join_side_stream() -> None:
+    """Make the current stream wait for all side-stream work (called once at the end of backward)."""
+    if _SIDE["stream"] is not None and _SIDE["used"]:
+        torch.cuda.current_stream().wait_stream(_SIDE["stream"])
+        _SIDE["used"] = False
+
 
 def current_tape() -> Optional[Tape]:
     return _TAPE

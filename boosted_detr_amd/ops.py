@@ -15,7 +15,7 @@ from typing import Optional
 import torch
 
 from . import kernels as K
-from .engine import Variable, current_tape
+from .engine import Variable, current_tape, on_side_stream
 
 _dropout_site = [0]
 _dropout_base_seed = [0x5EED]
@@ -131,19 +131,21 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
     def backward(g_out, acc=None):
         dy, dres = _bn_backward(_2d(g_out.contiguous()), out2d, y2d, mean, rstd, bn, relu, not use_batch, residual is not None)
         dy4 = dy.view(N, g.OH, g.OW, Kout)
-        if w.needs_grad:
-            s = GradSink(w)
-            K.conv2d_bwd_weight(x, dy4, g, dw=s.buf)
-            s.commit()
-        if b.needs_grad:
-            s = GradSink(b)
-            if use_batch:
-                # A bias in front of a batch-statistics BN has an exactly zero gradient: sum_rows(dy) =
-                # -rstd*gamma*mean(g*xhat)*sum(xhat) and sum(xhat) == 0.  (The fp64 oracle gives ~1e-15.)
-                K.zero_(s.buf)
-            else:
-                K.colsum(dy, out=s.buf)
-            s.commit()
+        if w.needs_grad or b.needs_grad:
+            with on_side_stream(x, dy):
+                if w.needs_grad:
+                    s = GradSink(w)
+                    K.conv2d_bwd_weight(x, dy4, g, dw=s.buf)
+                    s.commit()
+                if b.needs_grad:
+                    s = GradSink(b)
+                    if use_batch:
+                        # A bias in front of a batch-statistics BN has an exactly zero gradient: sum_rows(dy) =
+                        # -rstd*gamma*mean(g*xhat)*sum(xhat) and sum(xhat) == 0.  (The fp64 oracle gives ~1e-15.)
+                        K.zero_(s.buf)
+                    else:
+                        K.colsum(dy, out=s.buf)
+                    s.commit()
         dx = None
         if x_needs_grad:
             if acc is not None and acc[0] is not None:
@@ -175,14 +177,16 @@ def conv_act(x: torch.Tensor, w: Variable, b: Variable, stride: int, pad: int, a
             dpre = K.relu_bwd(y, g_out)
         else:
             dpre = g_out
-        if w.needs_grad:
-            s = GradSink(w)
-            K.conv2d_bwd_weight(x, dpre, g, dw=s.buf)
-            s.commit()
-        if b.needs_grad:
-            s = GradSink(b)
-            K.colsum(_2d(dpre), out=s.buf)
-            s.commit()
+        if w.needs_grad or b.needs_grad:
+            with on_side_stream(x, dpre):
+                if w.needs_grad:
+                    s = GradSink(w)
+                    K.conv2d_bwd_weight(x, dpre, g, dw=s.buf)
+                    s.commit()
+                if b.needs_grad:
+                    s = GradSink(b)
+                    K.colsum(_2d(dpre), out=s.buf)
+                    s.commit()
         return (_own(K.conv2d_bwd_data(dpre, w.value, g)),)
 
     _rec([y], [x], backward)
@@ -226,14 +230,16 @@ def dense(x: torch.Tensor, w: Variable, b: Variable, act: int = K.ACT_NONE) -> t
             g2d = K.relu_bwd(y2d, g2d)
         elif act == K.ACT_TANH:
             g2d = K.tanh_bwd(y2d, g2d)
-        if w.needs_grad:
-            s = GradSink(w)
-            K.linear_bwd_weight(g2d, x2d, dw=s.buf)
-            s.commit()
-        if b.needs_grad:
-            s = GradSink(b)
-            K.colsum(g2d, out=s.buf)
-            s.commit()
+        if w.needs_grad or b.needs_grad:
+            with on_side_stream(x2d, g2d):
+                if w.needs_grad:
+                    s = GradSink(w)
+                    K.linear_bwd_weight(g2d, x2d, dw=s.buf)
+                    s.commit()
+                if b.needs_grad:
+                    s = GradSink(b)
+                    K.colsum(g2d, out=s.buf)
+                    s.commit()
         return (_own(K.linear_bwd_data(g2d, w.value).view(x.shape)),)
 
     _rec([y], [x], backward)

@@ -21,7 +21,7 @@ import torch
 from . import _lib
 from . import kernels as K
 from . import ops
-from .engine import Layer, Tape, Variable, device, recording, to_device
+from .engine import Layer, Tape, Variable, device, join_side_stream, recording, to_device
 
 
 # ----------------------------------------------------------------------------------------
@@ -252,6 +252,7 @@ class Model(Layer):
         with recording(tape):
             y_pred = self(data, training=True)
         tape.backward({id(t): t for t in self._loss_roots})     # parameter gradients land in Variable.grad (ops.GradSink)
+        join_side_stream()                                      # weight-gradient GEMMs ran on the side stream
         return y_pred
 
     def train_step(self, data: dict) -> Dict[str, torch.Tensor]:
