@@ -220,7 +220,9 @@ _TAPE: Optional[Tape] = None
 # weight-gradient GEMMs are consumed by nobody until the optimizer runs.  They are launched on a
 # second HIP stream so that (a) their MFMA-bound workgroups fill the tails of the main stream's
 # kernels and (b) they overlap the HBM-bound BN/LayerNorm backward kernels of the earlier layers.
-_SIDE = {"stream": None, "enabled": True, "used": False}
+import os as _os
+
+_SIDE = {"stream": None, "enabled": _os.environ.get("BDETR_SIDE_STREAM", "1") != "0", "used": False}
 
 
 def side_stream() -> Optional["torch.cuda.Stream"]:
