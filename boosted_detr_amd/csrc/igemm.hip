@@ -411,7 +411,7 @@ TileChoice choose_tile(int I, int J, int zdim) {
         if (J <= 32) return {128, 32};
         return {forced_bm, forced_bn};
     }
-    // Measured on MI355X (scratch/gemm_bench.py): the 64x64 tile (4 workgroups per CU, 16 MFMAs per
+    // Measured on MI355X (tools/gemm_bench.py): the 64x64 tile (4 workgroups per CU, 16 MFMAs per
     // wave between barriers) beats 128x128 / 128x64 on every shape of this model (M <= 409600,
     // N <= 2048): 97-108 vs 51-95 TF/s; 128x128 only wins once there are >= ~16 tiles per CU.
     auto tiles = [&](int bm, int bn) { return cdiv64(I, bm) * cdiv64(J, bn) * zdim; };
