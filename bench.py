@@ -36,7 +36,7 @@ def synthetic_batch(cfg_mod, cfg, batch, max_objects, seed):
     return cfg_mod.make_batch(cfg, batch, max_objects, seed=seed)
 
 
-def make_batch(B, H, W, M, C, seed):
+def make_batch(B, H, W, M, C, seed, A=3):
     """SURVEY 8(d) synthetic inputs (same generator as oracle.make_batch, restated here so the
     timed path never imports the oracle)."""
     rng = np.random.Generator(np.random.PCG64(seed))
@@ -50,19 +50,44 @@ def make_batch(B, H, W, M, C, seed):
         category[b, :n] = rng.integers(2, C, size=n)
         k = rng.integers(0, 4, size=n)                      # <=3 attribute ids per object (COCO: A=3, weight 0)
         for m in range(n):
-            attribute[b, m, :k[m]] = rng.integers(2, 3, size=k[m])
+            attribute[b, m, :k[m]] = rng.integers(2, A, size=k[m])
         bbox[b, :n, 0:2] = rng.uniform(0.0, 0.6, size=(n, 2))
         bbox[b, :n, 2:4] = rng.uniform(0.05, 0.4, size=(n, 2))
     return {"image": image, "category": category, "attribute": attribute, "bbox": bbox, "num_objects": num_objects}
 
 
+def is_config2(args) -> bool:
+    return (args.model == "detr" and not args.fashionpedia and args.backbone == "ResNet" and args.image == 640
+            and not args.image_w and args.layers == 6 and args.queries == 100)
+
+
+def workload_name(args) -> str:
+    w = args.image_w or args.image
+    if is_config2(args):
+        tag = "configs[1]"
+    elif args.model == "boosted":
+        tag = "configs[2] variant"
+    elif args.backbone == "ResNet101":
+        tag = "configs[4] variant (no reference counterpart)"
+    else:
+        tag = "custom"
+    arch = (f"BoostedDETR {args.learners} weak learners" if args.model == "boosted" else f"DETR {args.layers} enc + {args.layers} dec")
+    heads = "Fashionpedia 46 categories / 294 attributes" if args.fashionpedia else "COCO-80"
+    return (f"{tag}: {arch}, {args.backbone}-50 backbone {args.image}x{w}, d=256 h=8, {args.queries} queries, {heads}, dropout 0.1, "
+            f"SGD-Nesterov clipnorm step").replace("ResNet101-50", "ResNet-101").replace("ResNet-50 backbone", "ResNet-50 backbone")
+
+
 def build_model(args):
     from boosted_detr_amd import parameters
+    from boosted_detr_amd.boosted_model import BoostedDETR
     from boosted_detr_amd.model import DETR
     from boosted_detr_amd.training import SGD, CosineDecayRestarts
-    model = DETR(num_object_preds=args.queries, image_size=(args.image, args.image), num_encoder_blocks=args.layers,
-                 num_encoder_heads=8, encoder_dim=256, num_decoder_blocks=args.layers, num_decoder_heads=8, decoder_dim=256,
-                 num_panoptic_heads=1, panoptic_dim=32, vocab_dict=parameters.COCO_VOCAB, attribute_weight=0.0)
+    vocab = parameters.synthetic_vocab(46, 294) if args.fashionpedia else parameters.COCO_VOCAB
+    cls = BoostedDETR if args.model == "boosted" else DETR
+    model = cls(num_object_preds=args.queries, image_size=(args.image, args.image_w or args.image), num_encoder_blocks=args.layers,
+                num_encoder_heads=8, encoder_dim=256, num_decoder_blocks=args.learners if args.model == "boosted" else args.layers,
+                num_decoder_heads=8, decoder_dim=256, num_panoptic_heads=1, panoptic_dim=32, vocab_dict=vocab,
+                attribute_weight=1.0 if args.fashionpedia else 0.0, backbone_name=args.backbone)
     # notebook cell 26: SGD(CosineDecayRestarts(1e-3, 4000, m_mul=.95, alpha=.1), momentum=.9, nesterov=True, clipnorm=.1)
     model.compile(optimizer=SGD(CosineDecayRestarts(1e-3, 4000, m_mul=0.95, alpha=0.1), momentum=0.9, nesterov=True, clipnorm=0.1))
     return model
@@ -126,6 +151,11 @@ def main():
     ap.add_argument("--image", type=int, default=640)
     ap.add_argument("--layers", type=int, default=6)
     ap.add_argument("--queries", type=int, default=100)
+    ap.add_argument("--image-w", type=int, default=0, help="image width when not square (config 5: --image 800 --image-w 1333)")
+    ap.add_argument("--model", choices=["detr", "boosted"], default="detr", help="configs[2]: --model boosted --learners 3 --fashionpedia")
+    ap.add_argument("--learners", type=int, default=3)
+    ap.add_argument("--fashionpedia", action="store_true", help="46 categories / 294 attributes, attribute_weight 1.0")
+    ap.add_argument("--backbone", default="ResNet", choices=["ResNet", "ResNet101"], help="configs[4]: ResNet101 (no reference counterpart)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -148,7 +178,8 @@ def main():
     L = _lib.lib()
 
     model = build_model(args)
-    host = make_batch(args.batch, args.image, args.image, 100, 82, seed=1234 + rank)
+    host = make_batch(args.batch, args.image, args.image_w or args.image, 100, 48 if args.fashionpedia else 82, seed=1234 + rank,
+                      A=296 if args.fashionpedia else 3)
     # inputs resident in HBM before the timed region (targets are pre-tokenised int ids)
     batch = {"image": to_device(host["image"]), "category": host["category"], "attribute": host["attribute"],
              "bbox": to_device(host["bbox"]), "num_objects": to_device(host["num_objects"], torch.int32)}
@@ -234,11 +265,9 @@ def main():
             "metric": METRIC, "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"configs[1]: DETR ResNet-50 {args.image}x{args.image}, {args.layers} enc + {args.layers} dec, d=256 h=8, "
-                                   f"{args.queries} queries, COCO-80, dropout 0.1, SGD-Nesterov clipnorm step",
-                       "per_gpu_batch": args.batch, "global_batch": global_batch, "parallelism": f"dp{world}",
-                       "gflop_per_image_algorithmic": GFLOP_PER_IMAGE},
-            "tflops_algorithmic": round(value * GFLOP_PER_IMAGE / 1e3, 2),
+            "config": {"workload": workload_name(args), "per_gpu_batch": args.batch, "global_batch": global_batch,
+                       "parallelism": f"dp{world}", "gflop_per_image_algorithmic": GFLOP_PER_IMAGE if is_config2(args) else None},
+            "tflops_algorithmic": round(value * GFLOP_PER_IMAGE / 1e3, 2) if is_config2(args) else None,
             "final_loss": round(logs.get("loss", float("nan")), 4),
             "roofline": roof,
             "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(args),
