@@ -116,14 +116,17 @@ def conv2d_bwd_data(dy, w, g: ConvGeom, dx: Optional[torch.Tensor] = None, accum
     return dx
 
 
-def conv2d_bwd_weight(x, dy, g: ConvGeom, dw: Optional[torch.Tensor] = None):
+def conv2d_bwd_weight(x, dy, g: ConvGeom, dw: Optional[torch.Tensor] = None, prezeroed: bool = False):
+    """prezeroed: dw already holds zeros (the optimizer's flat gradient buffer is cleared once per step),
+    so the split-K atomics need no per-tensor memset."""
     _chk(x, dy, dw)
     L = _lib.lib()
     d = g.desc()
     if dw is None:
         dw = empty(g.K, g.R, g.S, g.C, like=x)
+        prezeroed = False
     sk = L.bdetr_conv2d_bwd_weight_splitk(C.byref(d))
-    if sk > 1:
+    if sk > 1 and not prezeroed:
         check(L.bdetr_zero(_p(dw), dw.numel(), _stream()), "zero")
     check(L.bdetr_conv2d_bwd_weight(_p(x), _p(dy), _p(dw), C.byref(d), sk, _stream()), "conv2d_bwd_weight")
     return dw
@@ -165,14 +168,15 @@ def _auto_splitk(I, J, R) -> int:
     return sk
 
 
-def linear_bwd_weight(dy2d, x2d, dw=None):
+def linear_bwd_weight(dy2d, x2d, dw=None, prezeroed: bool = False):
     """dw[o][i] = sum_m dy[m][o] * x[m][i]."""
     M, O = dy2d.shape
     K = x2d.shape[1]
     if dw is None:
         dw = empty(O, K, like=dy2d)
+        prezeroed = False
     sk = _auto_splitk(O, K, M)
-    if sk > 1:
+    if sk > 1 and not prezeroed:
         check(_lib.lib().bdetr_zero(_p(dw), dw.numel(), _stream()), "zero")
     return gemm_raw(O, K, M, dy2d, O, False, x2d, K, False, dw, K, splitk=sk)
 

@@ -61,7 +61,7 @@ class GradSink:
         if not var.needs_grad:
             self.mode, self.buf = "drop", torch.empty_like(var.value)
         elif var.grad is None and var.grad_buf is not None:
-            self.mode, self.buf = "direct", var.grad_buf
+            self.mode, self.buf = "direct", var.grad_buf      # zero-filled at the start of the step (Model.forward_backward)
         else:
             self.mode, self.buf = "temp", torch.empty_like(var.value)
 
@@ -135,14 +135,15 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
             with on_side_stream(x, dy):
                 if w.needs_grad:
                     s = GradSink(w)
-                    K.conv2d_bwd_weight(x, dy4, g, dw=s.buf)
+                    K.conv2d_bwd_weight(x, dy4, g, dw=s.buf, prezeroed=s.mode == "direct")
                     s.commit()
                 if b.needs_grad:
                     s = GradSink(b)
                     if use_batch:
                         # A bias in front of a batch-statistics BN has an exactly zero gradient: sum_rows(dy) =
                         # -rstd*gamma*mean(g*xhat)*sum(xhat) and sum(xhat) == 0.  (The fp64 oracle gives ~1e-15.)
-                        K.zero_(s.buf)
+                        if s.mode != "direct":
+                            K.zero_(s.buf)
                     else:
                         K.colsum(dy, out=s.buf)
                     s.commit()
@@ -181,7 +182,7 @@ def conv_act(x: torch.Tensor, w: Variable, b: Variable, stride: int, pad: int, a
             with on_side_stream(x, dpre):
                 if w.needs_grad:
                     s = GradSink(w)
-                    K.conv2d_bwd_weight(x, dpre, g, dw=s.buf)
+                    K.conv2d_bwd_weight(x, dpre, g, dw=s.buf, prezeroed=s.mode == "direct")
                     s.commit()
                 if b.needs_grad:
                     s = GradSink(b)
@@ -234,7 +235,7 @@ def dense(x: torch.Tensor, w: Variable, b: Variable, act: int = K.ACT_NONE) -> t
             with on_side_stream(x2d, g2d):
                 if w.needs_grad:
                     s = GradSink(w)
-                    K.linear_bwd_weight(g2d, x2d, dw=s.buf)
+                    K.linear_bwd_weight(g2d, x2d, dw=s.buf, prezeroed=s.mode == "direct")
                     s.commit()
                 if b.needs_grad:
                     s = GradSink(b)

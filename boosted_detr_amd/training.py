@@ -248,6 +248,8 @@ class Model(Layer):
         ops.set_dropout_seed(0x5EED + self.steps_done)
         for v in self.variables:
             v.reset_grad()
+        if self.optimizer is not None and getattr(self.optimizer, "flat_grad", None) is not None:
+            self.optimizer.flat_grad.zero_()     # ONE memset for all gradients (split-K GEMMs accumulate into zeros)
         tape = Tape()
         with recording(tape):
             y_pred = self(data, training=True)
