@@ -58,6 +58,7 @@ SIGNATURES = {
     "bdetr_conv2d_bwd_weight": (I, [P, P, P, C.POINTER(ConvDesc), I, P]),
     "bdetr_conv2d_bwd_weight_splitk": (I, [C.POINTER(ConvDesc)]),
     "bdetr_gemm": (I, [C.POINTER(GemmDesc), P]),
+    "bdetr_gemm_grouped": (I, [C.POINTER(GemmDesc), I, P]),
     "bdetr_colsum_chunks": (I, [L]),
     "bdetr_colsum": (I, [P, L, I, P, P, P]),
     "bdetr_colstats": (I, [P, L, I, P, P, P]),

@@ -59,6 +59,10 @@ struct DenseLoader {
     static __device__ __forceinline__ const float* batch_base(const Op& op, int b0, int b1) {
         return op.p + (int64_t)b0 * op.s0 + (int64_t)b1 * op.s1;
     }
+    static __device__ __forceinline__ void regroup(Op& op, const float* p, int x_extent, bool rc) {
+        op.p = p;
+        if (x_extent >= 0) { if (rc) op.rows = x_extent; else op.cols = x_extent; }
+    }
     static __device__ __forceinline__ Ctx row_ctx(const Op& op, int row, int row_limit) {
         Ctx c; c.ok = row < row_limit; c.off = (unsigned)row * (unsigned)op.ld; return c;
     }
@@ -78,6 +82,7 @@ struct PatchLoader {
     using Op = PatchOp;
     struct Ctx { int nbase; int ih0, iw0; bool ok; };
     static __device__ __forceinline__ const float* batch_base(const Op& op, int, int) { return op.p; }
+    static __device__ __forceinline__ void regroup(Op&, const float*, int, bool) {}
     static __device__ __forceinline__ Ctx row_ctx(const Op& op, int row, int row_limit) {
         Ctx c; c.ok = row < row_limit;
         int ohw = op.OH * op.OW;
@@ -101,6 +106,7 @@ struct WFlipLoader {
     using Op = WFlipOp;
     struct Ctx { unsigned off; bool ok; };
     static __device__ __forceinline__ const float* batch_base(const Op& op, int, int) { return op.p; }
+    static __device__ __forceinline__ void regroup(Op&, const float*, int, bool) {}
     static __device__ __forceinline__ Ctx row_ctx(const Op& op, int row, int row_limit) {
         Ctx c; c.ok = row < row_limit;
         int tap = row / op.K; int k = row - tap * op.K;
@@ -129,6 +135,10 @@ struct GemmParams {
     int vec_store;                      // C rows are 16-byte aligned and J % 4 == 0: LDS-transposed float4 stores
     int rowmap;                         // scatter C rows through a strided-pixel map (conv s>1 bwd-data)
     int rm_OW, rm_OHOW, rm_H, rm_W, rm_stride;
+    // grouped launch (dense operands only): blockIdx.z selects one of up to 4 independent problems that
+    // share J, R and the epilogue flags but have their own pointers and row count (Q/K/V projections)
+    int ngroups;
+    const float* ga[4]; const float* gb[4]; float* gc[4]; const float* gbias[4]; int gI[4];
 };
 
 template <int BX, bool RC>
@@ -180,7 +190,19 @@ void igemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
     const int i0 = tile_i * BM, j0 = tile_j * BN;
 
     int b0 = 0, b1 = 0, r_begin = 0, r_end = g.R;
-    if (g.splitk > 1) {
+    if (g.ngroups > 0) {
+        // select with constant indices: a runtime index into kernel-argument arrays would push the whole
+        // parameter block to scratch memory (measured: every igemm launch +25 %)
+        const int z = blockIdx.z;
+#define BDETR_PICK(arr) (z == 0 ? g.arr[0] : z == 1 ? g.arr[1] : z == 2 ? g.arr[2] : g.arr[3])
+        g.I = BDETR_PICK(gI); g.c = BDETR_PICK(gc); g.bias = BDETR_PICK(gbias);
+        const float* pa = BDETR_PICK(ga);
+        const float* pb = BDETR_PICK(gb);
+#undef BDETR_PICK
+        if (i0 >= g.I) return;                                  // this problem has fewer row tiles (uniform per block)
+        LA::regroup(opa, pa, g.I, A_RC);
+        LB::regroup(opb, pb, -1, B_RC);
+    } else if (g.splitk > 1) {
         r_begin = blockIdx.z * g.r_chunk;
         r_end = min(g.R, r_begin + g.r_chunk);
     } else {
@@ -526,6 +548,42 @@ extern "C" int bdetr_prof_read(double* total_ms, int64_t* launches, double* flop
     if (launches) *launches = (int64_t)g_prof_recs.size();
     if (flops) *flops = fl;
     return 0;
+}
+
+// Up to 4 independent dense GEMMs with the same J, R, operand flavours and epilogue in ONE launch
+// (gridDim.z = n): the Q/K/V projections of an attention block and their input gradients.
+extern "C" int bdetr_gemm_grouped(const bdetr_gemm_desc* d, int n, void* stream) {
+    BDETR_CHECK_ARG(d && n >= 1 && n <= 4, "bdetr_gemm_grouped: 1..4 problems");
+    GemmParams g; init_params(g);
+    int maxI = 0;
+    bool v4 = true;
+    for (int k = 0; k < n; ++k) {
+        const bdetr_gemm_desc& e = d[k];
+        BDETR_CHECK_ARG(e.a && e.b && e.c && e.I > 0, "bdetr_gemm_grouped: null pointer / empty problem %d", k);
+        BDETR_CHECK_ARG(e.J == d[0].J && e.R == d[0].R && e.a_rcontig == d[0].a_rcontig && e.b_rcontig == d[0].b_rcontig &&
+                        e.act == d[0].act && e.alpha == d[0].alpha && e.accumulate == d[0].accumulate &&
+                        e.lda == d[0].lda && e.ldb == d[0].ldb && e.ldc == d[0].ldc,
+                        "bdetr_gemm_grouped: problems must share J, R, leading dimensions, flavours and epilogue");
+        BDETR_CHECK_ARG((e.nb0 <= 1) && (e.nb1 <= 1) && e.splitk <= 1, "bdetr_gemm_grouped: no batching / split-K inside a group");
+        g.ga[k] = e.a; g.gb[k] = e.b; g.gc[k] = e.c; g.gbias[k] = e.bias; g.gI[k] = e.I;
+        if (e.I > maxI) maxI = e.I;
+        v4 = v4 && aligned16(e.a) && aligned16(e.b) && aligned16(e.c);
+    }
+    const bdetr_gemm_desc& f = d[0];
+    BDETR_CHECK_ARG(v4 && f.lda % 4 == 0 && f.ldb % 4 == 0 && f.ldc % 4 == 0 && f.J % 4 == 0 && f.R % 4 == 0,
+                    "bdetr_gemm_grouped: operands must be 16-byte aligned with dimensions that are multiples of 4");
+    g.ngroups = n;
+    g.I = maxI; g.J = f.J; g.R = f.R;
+    g.c = f.c; g.ldc = f.ldc; g.bias = f.bias; g.alpha = f.alpha; g.act = f.act;
+    g.mode = f.accumulate ? ST_ACCUM : ST_STORE;
+    DenseOp a{f.a, f.lda, 0, 0, f.a_rcontig ? maxI : f.R, f.a_rcontig ? f.R : maxI};
+    DenseOp b{f.b, f.ldb, 0, 0, f.b_rcontig ? f.J : f.R, f.b_rcontig ? f.R : f.J};
+    hipStream_t st = (hipStream_t)stream;
+    const bool arc = f.a_rcontig != 0, brc = f.b_rcontig != 0;
+    if (arc && brc)   return launch_any<DenseLoader<4>, true, DenseLoader<4>, true>(a, b, g, n, st);
+    if (arc && !brc)  return launch_any<DenseLoader<4>, true, DenseLoader<4>, false>(a, b, g, n, st);
+    if (!arc && !brc) return launch_any<DenseLoader<4>, false, DenseLoader<4>, false>(a, b, g, n, st);
+    return launch_any<DenseLoader<4>, false, DenseLoader<4>, true>(a, b, g, n, st, true);
 }
 
 extern "C" int bdetr_gemm(const bdetr_gemm_desc* d, void* stream) {

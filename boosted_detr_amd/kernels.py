@@ -144,6 +144,32 @@ def gemm_raw(I, J, R, a, lda, a_rc, b, ldb, b_rc, c, ldc, *, nb0=1, nb1=1, sa=(0
     return c
 
 
+def gemm_grouped(descs):
+    """descs: list of (I, J, R, a, lda, a_rc, b, ldb, b_rc, c, ldc, bias, act, accumulate)."""
+    arr = (GemmDesc * len(descs))()
+    for k, (I, J, R, a, lda, a_rc, b, ldb, b_rc, c, ldc, bias, act, acc) in enumerate(descs):
+        _chk(a, b, c, bias)
+        arr[k] = GemmDesc(I, J, R, 1, 1, _p(a), lda, 0, 0, int(a_rc), _p(b), ldb, 0, 0, int(b_rc), _p(c), ldc, 0, 0, _p(bias), 1.0, act,
+                          int(acc), 1)
+    check(_lib.lib().bdetr_gemm_grouped(arr, len(descs), _stream()), "gemm_grouped")
+
+
+def linear_fwd_group(xs, ws, biases, act=ACT_NONE):
+    """[x_k @ w_k^T + b_k for k]: same in/out widths, row counts may differ; one launch."""
+    K_, O = xs[0].shape[1], ws[0].shape[0]
+    ys = [empty(x.shape[0], O, like=x) for x in xs]
+    gemm_grouped([(x.shape[0], O, K_, x, K_, True, w, K_, True, y, O, b, act, False) for x, w, b, y in zip(xs, ws, biases, ys)])
+    return ys
+
+
+def linear_bwd_data_group(dys, ws):
+    """[dy_k @ w_k for k] in one launch."""
+    O, K_ = ws[0].shape
+    dxs = [empty(dy.shape[0], K_, like=dy) for dy in dys]
+    gemm_grouped([(dy.shape[0], K_, O, dy, O, True, w, K_, False, dx, K_, None, ACT_NONE, False) for dy, w, dx in zip(dys, ws, dxs)])
+    return dxs
+
+
 def linear_fwd(x2d, w, bias, act=ACT_NONE):
     """y[m][o] = act(sum_i x[m][i] * w[o][i] + bias[o]);  w is [out][in]."""
     M, K = x2d.shape

@@ -247,6 +247,37 @@ def dense(x: torch.Tensor, w: Variable, b: Variable, act: int = K.ACT_NONE) -> t
     return y
 
 
+def dense_group(xs, ws, bs):
+    """Independent Dense layers of identical width (the Q/K/V projections of an attention block,
+    transformers.py:68-70) as ONE grouped GEMM launch forward and one for the input gradients."""
+    x2 = [_2d(x) for x in xs]
+    aligned = all(t.data_ptr() % 16 == 0 for t in x2) and x2[0].shape[1] % 4 == 0 and ws[0].value.shape[0] % 4 == 0
+    same = all(w.value.shape == ws[0].value.shape for w in ws)
+    if not (aligned and same) or len(xs) > 4:
+        return [dense(x, w, b) for x, w, b in zip(xs, ws, bs)]
+    y2 = K.linear_fwd_group(x2, [w.value for w in ws], [b.value for b in bs])
+    ys = [y.view(*x.shape[:-1], y.shape[1]) for y, x in zip(y2, xs)]
+
+    def backward(*gs):
+        g2 = [_2d(g.contiguous()) for g in gs]
+        for g, x, w, b in zip(g2, x2, ws, bs):
+            if w.needs_grad or b.needs_grad:
+                with on_side_stream(x, g):
+                    if w.needs_grad:
+                        s = GradSink(w)
+                        K.linear_bwd_weight(g, x, dw=s.buf, prezeroed=s.mode == "direct")
+                        s.commit()
+                    if b.needs_grad:
+                        s = GradSink(b)
+                        K.colsum(g, out=s.buf)
+                        s.commit()
+        dxs = K.linear_bwd_data_group(g2, [w.value for w in ws])
+        return tuple(_own(dx.view(x.shape)) for dx, x in zip(dxs, xs))
+
+    _rec(ys, list(xs), backward)
+    return ys
+
+
 def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     out = K.add(a, b)
     _rec([out], [a, b], lambda g: (g, g))        # shared tensor: NOT owned

@@ -63,9 +63,9 @@ class MultiheadAttention(Layer):
         if attention_mask is not None:
             raise NotImplementedError("the hot path always calls MultiheadAttention with attention_mask=None")
         query, key, value = inputs
-        q = self.QueryProjection(query)
-        k = self.KeyProjection(key)
-        v = self.ValueProjection(value)
+        q, k, v = ops.dense_group([query, key, value],
+                                  [self.QueryProjection.kernel, self.KeyProjection.kernel, self.ValueProjection.kernel],
+                                  [self.QueryProjection.bias, self.KeyProjection.bias, self.ValueProjection.bias])
         o = ops.attention_core(q, k, v, self.num_attention_heads)          # [B,h,q,d]
         B, h, nq, d = o.shape
         o = ops.reshape(o, (B, nq, h * d))                                  # ReshapePreOutput: no permute (line 100)

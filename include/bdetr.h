@@ -99,6 +99,10 @@ typedef struct {
     const float* bias; float alpha; int act; int accumulate; int splitk;
 } bdetr_gemm_desc;
 int bdetr_gemm(const bdetr_gemm_desc* g, void* stream);
+/* n (1..4) independent GEMMs that share J, R, leading dimensions, operand flavours and epilogue flags
+ * (their pointers, bias and row count I may differ) in ONE launch - the Q/K/V projections of an
+ * attention block (transformers.py:68-70) and their input gradients.  No batching / split-K inside. */
+int bdetr_gemm_grouped(const bdetr_gemm_desc* g, int n, void* stream);
 
 /* column sums: out[j] = sum_i x[i][j]  (bias gradients; Keras autodiff of Dense/Conv bias).
  * Deterministic two-level reduction; ws: cols * bdetr_colsum_chunks(rows) floats. */

@@ -278,3 +278,18 @@ def test_image_prep(cuda):
     # resize: the uint8 truncation may flip by one unit where the interpolant lands within round-off of an integer
     diff = (out2[..., :3] - ref2).abs()
     assert diff.max() <= 1.0 and (diff > 0).double().mean() < 1e-3
+
+
+def test_gemm_grouped_qkv(cuda):
+    """Three projections with different inputs / weights / row counts in one launch (fwd and input grads)."""
+    from boosted_detr_amd import kernels as k
+    xs = [rnd(1600, 256, seed=1), rnd(6400, 256, seed=2), rnd(6400, 256, seed=3)]
+    ws = [rnd(256, 256, seed=4, scale=1 / 16), rnd(256, 256, seed=5, scale=1 / 16), rnd(256, 256, seed=6, scale=1 / 16)]
+    bs = [rnd(256, seed=7), rnd(256, seed=8), rnd(256, seed=9)]
+    ys = k.linear_fwd_group([dev(x) for x in xs], [dev(w) for w in ws], [dev(b) for b in bs])
+    for y, x, w, b in zip(ys, xs, ws, bs):
+        close(y, x.double() @ w.double().T + b.double())
+    dys = [rnd(1600, 256, seed=10), rnd(6400, 256, seed=11), rnd(6400, 256, seed=12)]
+    dxs = k.linear_bwd_data_group([dev(d) for d in dys], [dev(w) for w in ws])
+    for dx, dy, w in zip(dxs, dys, ws):
+        close(dx, dy.double() @ w.double())
