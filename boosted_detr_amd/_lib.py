@@ -70,6 +70,9 @@ SIGNATURES = {
     "bdetr_bn_bwd": (I, [P, P, P, P, P, P, P, I, I, P, P, P, P, P, L, I, P]),
     "bdetr_maxpool3x3s2_fwd": (I, [P, P, I, I, I, I, I, I, P]),
     "bdetr_maxpool3x3s2_bwd": (I, [P, P, P, P, I, I, I, I, I, I, P]),
+    "bdetr_attention_head_dim": (I, []),
+    "bdetr_attention_fwd": (I, [P, P, P, P, P, I, I, I, I, F, P]),
+    "bdetr_attention_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, P]),
     "bdetr_softmax_rows_fwd": (I, [P, P, L, I, F, P]),
     "bdetr_softmax_rows_bwd": (I, [P, P, P, L, I, F, P]),
     "bdetr_add_dropout_layernorm_fwd": (I, [P, P, P, P, P, P, P, L, I, F, F, U64, P]),

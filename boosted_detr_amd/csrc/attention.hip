@@ -1,0 +1,257 @@
+// attention.hip - fused multi-head attention core for gfx950 (head dim 32, exact fp32 MFMA).
+//
+// Replaces transformers.py:86-97 (MatMulQueryKey -> Rescaling(1/sqrt(d)) -> softmax -> mask of ones
+// -> MatMulQueryValue) and its autodiff.  The [B,h,q,k] score tensor is never written to HBM:
+// K/V (forward) or the streamed operand pair (backward) move through LDS in 64-row chunks and the
+// softmax runs online in registers.
+//
+// Orientation trick (64-lane wavefronts, v_mfma_f32_32x32x2_f32): every product is arranged so that
+// the softmax axis sits on the MFMA *row* index, which the 32x32 accumulator layout keeps inside a
+// lane's 16 registers (+ the partner lane l^32).  Forward computes S^T = K Q^T (lane column = one
+// query), so the row max / row sum are 15 in-register ops and one shuffle; the exponentiated tile is
+// already the B operand of O^T += V^T P^T - P never touches LDS.  The backward uses the same layout
+// twice: once with queries on the columns (dQ) and once with keys on the columns (dK, dV).
+//
+// Layouts: q/k/v/dq/dk/dv are [B, n, h*32] (head h at columns 32h..32h+31, exactly what the Dense
+// projections produce); o/do are [B, h, q, 32] (the layout the reference reshapes without a
+// permute, transformers.py:100); lse/dvec are [B, h, q].
+#include "common.h"
+
+namespace {
+
+constexpr int AD = 32;            // head dimension
+constexpr int ALD = AD + 4;       // LDS row stride (floats): conflict-free 16-byte row reads
+constexpr int CH = 64;            // streamed rows per chunk
+constexpr int COLS_PER_BLOCK = 128;
+
+__device__ __forceinline__ int crow(int e, int lh) { return (e & 3) + 8 * (e >> 2) + 4 * lh; }   // accumulator row of register e
+
+// rows [r0, r0+64) of a strided matrix -> LDS [64][ALD]; rows >= n are zero-filled
+__device__ __forceinline__ void load_chunk(float* __restrict__ lds, const float* __restrict__ base, int64_t stride, int r0, int n) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int v = threadIdx.x + 256 * p;
+        const int row = v >> 3, c4 = v & 7;
+        f32x4 val = {0.f, 0.f, 0.f, 0.f};
+        if (r0 + row < n) val = *reinterpret_cast<const f32x4*>(base + (int64_t)(r0 + row) * stride + 4 * c4);
+        *reinterpret_cast<f32x4*>(lds + row * ALD + 4 * c4) = val;
+    }
+}
+
+// 16 values X[col][16*lh + s] of this lane's column (or zeros when the column is out of range)
+__device__ __forceinline__ void load_col_regs(float (&r)[16], const float* __restrict__ base, int64_t stride, int col, bool ok, int lh) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ok) v = *reinterpret_cast<const f32x4*>(base + (int64_t)col * stride + 16 * lh + 4 * c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[4 * c + e] = v[e];
+    }
+}
+
+// tile[i][j] = sum_d R[32t+i][d] * C[j][d]  with C held per lane as creg[s] = C[j][16*lh+s]
+__device__ __forceinline__ f32x16 row_times_col(const float* __restrict__ sR, int t, const float (&creg)[16], int li, int lh) {
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    f32x4 a[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) a[c] = *reinterpret_cast<const f32x4*>(sR + (32 * t + li) * ALD + 16 * lh + 4 * c);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s >> 2][s & 3], creg[s], acc, 0, 0, 0);
+    return acc;
+}
+
+// acc[d][j] += sum_r R[32t+r][d] * T[r][j]   with T in accumulator layout (register e = row crow(e,lh))
+__device__ __forceinline__ void accumulate_rt_tile(f32x16& acc, const float* __restrict__ sR, int t, const f32x16& tile, int li, int lh) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const float a = sR[(32 * t + crow(e, lh)) * ALD + li];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, tile[e], acc, 0, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                       float* __restrict__ o, float* __restrict__ lse,
+                                                       int h, int nq, int nk, float scale) {
+    __shared__ __attribute__((aligned(16))) float sK[CH * ALD];
+    __shared__ __attribute__((aligned(16))) float sV[CH * ALD];
+    const int b = blockIdx.z, head = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+    const int64_t D = (int64_t)h * AD;
+    const int qi = blockIdx.x * COLS_PER_BLOCK + wave * 32 + li;
+    const bool qok = qi < nq;
+    float qr[16];
+    load_col_regs(qr, q + (int64_t)b * nq * D + head * AD, D, qi, qok, lh);
+    const float* kbase = k + (int64_t)b * nk * D + head * AD;
+    const float* vbase = v + (int64_t)b * nk * D + head * AD;
+
+    f32x16 oacc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) oacc[e] = 0.f;
+    float m = -INFINITY, l = 0.f;
+
+    for (int c0 = 0; c0 < nk; c0 += CH) {
+        __syncthreads();
+        load_chunk(sK, kbase, D, c0, nk);
+        load_chunk(sV, vbase, D, c0, nk);
+        __syncthreads();
+        f32x16 s[2];
+        float cmax = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            s[t] = row_times_col(sK, t, qr, li, lh);               // S^T tile: rows = keys, column = this lane's query
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float val = (c0 + 32 * t + crow(e, lh) < nk) ? s[t][e] * scale : -INFINITY;
+                s[t][e] = val;
+                cmax = fmaxf(cmax, val);
+            }
+        }
+        cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
+        const float mn = fmaxf(m, cmax);
+        const float alpha = expf(m - mn);
+        float psum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { const float p = expf(s[t][e] - mn); s[t][e] = p; psum += p; }
+        psum += __shfl_xor(psum, 32, 64);
+        l = l * alpha + psum;
+        m = mn;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[e] *= alpha;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) accumulate_rt_tile(oacc, sV, t, s[t], li, lh);    // O^T += V^T P^T
+    }
+    if (qok) {
+        const float inv = 1.0f / l;
+        float* orow = o + (((int64_t)b * h + head) * nq + qi) * AD;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) orow[crow(e, lh)] = oacc[e] * inv;
+        if (lh == 0) lse[((int64_t)b * h + head) * nq + qi] = m + logf(l);
+    }
+}
+
+// dvec[row] = sum_d do[row][d] * o[row][d]   (rows = B*h*q, 32 columns): 8 lanes per row
+__global__ __launch_bounds__(256) void attn_dvec_kernel(const float* __restrict__ o, const float* __restrict__ d_o, float* __restrict__ dvec, int64_t rows) {
+    const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3;
+    const int c4 = threadIdx.x & 7;
+    float s = 0.f;
+    if (row < rows) {
+        const f32x4 a = reinterpret_cast<const f32x4*>(o)[row * 8 + c4], g = reinterpret_cast<const f32x4*>(d_o)[row * 8 + c4];
+        s = a[0] * g[0] + a[1] * g[1] + a[2] * g[2] + a[3] * g[3];
+    }
+    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+    if (row < rows && c4 == 0) dvec[row] = s;
+}
+
+// KCOL == false: columns = queries, streamed rows = keys     -> out1 = dQ
+// KCOL == true : columns = keys,    streamed rows = queries  -> out1 = dK, out2 = dV
+template <bool KCOL>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                       const float* __restrict__ d_o, const float* __restrict__ lse, const float* __restrict__ dvec,
+                                                       float* __restrict__ out1, float* __restrict__ out2,
+                                                       int h, int nq, int nk, float scale) {
+    __shared__ __attribute__((aligned(16))) float sR1[CH * ALD];
+    __shared__ __attribute__((aligned(16))) float sR2[CH * ALD];
+    __shared__ float sL[CH], sD[CH];
+    const int b = blockIdx.z, head = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+    const int64_t D = (int64_t)h * AD;
+    const int ncol = KCOL ? nk : nq, nrow = KCOL ? nq : nk;
+    const int ci = blockIdx.x * COLS_PER_BLOCK + wave * 32 + li;
+    const bool cok = ci < ncol;
+    const int64_t bh = (int64_t)b * h + head;
+
+    // column-side operands in registers
+    const float* c1base = (KCOL ? k : q) + (int64_t)b * ncol * D + head * AD;
+    const float* c2base = KCOL ? (v + (int64_t)b * nk * D + head * AD) : (d_o + bh * nq * AD);
+    const int64_t c2stride = KCOL ? D : AD;
+    float c1r[16], c2r[16];
+    load_col_regs(c1r, c1base, D, ci, cok, lh);
+    load_col_regs(c2r, c2base, c2stride, ci, cok, lh);
+    // streamed row-side operands
+    const float* r1base = (KCOL ? q : k) + (int64_t)b * nrow * D + head * AD;
+    const float* r2base = KCOL ? (d_o + bh * nq * AD) : (v + (int64_t)b * nk * D + head * AD);
+    const int64_t r2stride = KCOL ? AD : D;
+
+    float Lcol = 0.f, Dcol = 0.f;
+    if (!KCOL && cok) { Lcol = lse[bh * nq + ci]; Dcol = dvec[bh * nq + ci]; }
+
+    f32x16 acc1, acc2;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc1[e] = 0.f; acc2[e] = 0.f; }
+
+    for (int c0 = 0; c0 < nrow; c0 += CH) {
+        __syncthreads();
+        load_chunk(sR1, r1base, D, c0, nrow);
+        load_chunk(sR2, r2base, r2stride, c0, nrow);
+        if (KCOL && threadIdx.x < CH) {
+            const int qi = c0 + threadIdx.x;
+            sL[threadIdx.x] = qi < nq ? lse[bh * nq + qi] : 0.f;
+            sD[threadIdx.x] = qi < nq ? dvec[bh * nq + qi] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x16 S = row_times_col(sR1, t, c1r, li, lh);      // scores      (rows = streamed side)
+            f32x16 G = row_times_col(sR2, t, c2r, li, lh);      // dP          (same orientation)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int r = 32 * t + crow(e, lh);
+                const float Lq = KCOL ? sL[r] : Lcol, Dq = KCOL ? sD[r] : Dcol;
+                const float p = (c0 + r < nrow) ? expf(S[e] * scale - Lq) : 0.f;
+                S[e] = p * (G[e] - Dq) * scale;                  // dS (gradient w.r.t. the unscaled product)
+                G[e] = p;
+            }
+            accumulate_rt_tile(acc1, sR1, t, S, li, lh);         // dQ^T += K^T dS^T   |  dK^T += Q^T dS
+            if (KCOL) accumulate_rt_tile(acc2, sR2, t, G, li, lh);   // dV^T += dO^T P
+        }
+    }
+    if (cok) {
+        float* o1 = out1 + ((int64_t)b * ncol + ci) * D + head * AD;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o1[crow(e, lh)] = acc1[e];
+        if (KCOL) {
+            float* o2 = out2 + ((int64_t)b * ncol + ci) * D + head * AD;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o2[crow(e, lh)] = acc2[e];
+        }
+    }
+}
+
+int check_attn(const void* a, const void* b, const void* c, int B, int h, int nq, int nk, const char* who) {
+    BDETR_CHECK_ARG(a && b && c, "%s: null pointer", who);
+    BDETR_CHECK_ARG(B > 0 && h > 0 && nq > 0 && nk > 0 && B <= 65535 && h <= 65535, "%s: bad sizes B=%d h=%d nq=%d nk=%d", who, B, h, nq, nk);
+    BDETR_CHECK_ARG(((uintptr_t)a & 15) == 0 && ((uintptr_t)b & 15) == 0 && ((uintptr_t)c & 15) == 0, "%s: operands must be 16-byte aligned", who);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int bdetr_attention_head_dim(void) { return AD; }
+
+extern "C" int bdetr_attention_fwd(const float* q, const float* k, const float* v, float* o, float* lse,
+                                   int B, int h, int nq, int nk, float scale, void* stream) {
+    if (int e = check_attn(q, k, v, B, h, nq, nk, "bdetr_attention_fwd")) return e;
+    BDETR_CHECK_ARG(o && lse, "bdetr_attention_fwd: null output");
+    dim3 grid((nq + COLS_PER_BLOCK - 1) / COLS_PER_BLOCK, h, B);
+    hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, q, k, v, o, lse, h, nq, nk, scale);
+    return bdetr_launch_status("attention_fwd");
+}
+
+extern "C" int bdetr_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* d_o,
+                                   const float* lse, float* dq, float* dk, float* dv, float* dvec_ws,
+                                   int B, int h, int nq, int nk, float scale, void* stream) {
+    if (int e = check_attn(q, k, v, B, h, nq, nk, "bdetr_attention_bwd")) return e;
+    BDETR_CHECK_ARG(o && d_o && lse && dq && dk && dv && dvec_ws, "bdetr_attention_bwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t rows = (int64_t)B * h * nq;
+    hipLaunchKernelGGL(attn_dvec_kernel, dim3((unsigned)((rows * 8 + 255) / 256)), dim3(256), 0, st, o, d_o, dvec_ws, rows);
+    hipLaunchKernelGGL((attn_bwd_kernel<false>), dim3((nq + COLS_PER_BLOCK - 1) / COLS_PER_BLOCK, h, B), dim3(256), 0, st,
+                       q, k, v, d_o, lse, dvec_ws, dq, (float*)nullptr, h, nq, nk, scale);
+    hipLaunchKernelGGL((attn_bwd_kernel<true>), dim3((nk + COLS_PER_BLOCK - 1) / COLS_PER_BLOCK, h, B), dim3(256), 0, st,
+                       q, k, v, d_o, lse, dvec_ws, dk, dv, h, nq, nk, scale);
+    return bdetr_launch_status("attention_bwd");
+}

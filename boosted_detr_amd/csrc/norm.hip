@@ -379,6 +379,10 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
     for (int k = 0; k < NPER; ++k) { const int c = lane + 64 * k; if (c < cols) ds[row * cols + c] = scale * pv[k] * (dv[k] - dot); }
 }
 
+// row chunks so that (column blocks x chunks) ~ 2048 workgroups: wide tensors need few chunks, which keeps the
+// fixed-order fp64 fold of the partials short
+int64_t chunks_for_width(int gx) { int64_t c = 2048 / (gx > 0 ? gx : 1); return c < 32 ? 32 : (c > 512 ? 512 : c); }
+
 int64_t chunk_rows_for(int64_t rows, int64_t maxchunks, int64_t minrows) {
     int64_t rpc = cdiv64(rows, maxchunks);
     if (rpc < minrows) rpc = minrows;
@@ -419,7 +423,7 @@ extern "C" int bdetr_bn_stats(const float* x, int64_t rows, int C, const float* 
 extern "C" int bdetr_colstats(const float* x, int64_t rows, int C, float* part_sum, float* part_sq, void* stream) {
     BDETR_CHECK_ARG(x && part_sum && part_sq && rows > 0 && C > 0 && C % 4 == 0, "bdetr_colstats: bad arguments (C %% 4 == 0 required)");
     ColGeom g = col_geom(C);
-    int64_t rpc = chunk_rows_for(rows, 512, 64);
+    int64_t rpc = chunk_rows_for(rows, 512, 64);     // must match bdetr_bn_bwd_chunks(rows): the caller sizes part_* with it
     int nch = (int)cdiv64(rows, rpc);
     StatFn f{x, C};
     hipLaunchKernelGGL((colreduce2_kernel<StatFn>), dim3(g.gx, nch), dim3(256), 0, (hipStream_t)stream, f, rows, C, g.tx, rpc, part_sum, part_sq);
@@ -451,7 +455,7 @@ extern "C" int bdetr_bn_bwd(const float* dout, const float* out, const float* x,
     BDETR_CHECK_ARG(!relu || out || beta, "bdetr_bn_bwd: relu needs the forward output, or beta to recompute the mask from x");
     hipStream_t st = (hipStream_t)stream;
     ColGeom g = col_geom(C);
-    int64_t rpc = chunk_rows_for(rows, 512, 64);
+    int64_t rpc = chunk_rows_for(rows, chunks_for_width(g.gx), 64);   // <= bdetr_bn_bwd_chunks(rows), which sizes ws
     int nch = (int)cdiv64(rows, rpc);
     float* pa = ws; float* pb = ws + (int64_t)nch * C;
     BnBwdFn f{dout, out, x, mean, rstd, gamma, beta, C, relu};

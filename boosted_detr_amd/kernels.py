@@ -295,6 +295,28 @@ def maxpool_bwd(x, y, dy):
     return dx
 
 
+def attention_fwd(q, k, v, heads, scale):
+    """q [B,nq,h*32], k/v [B,nk,h*32] -> o [B,h,nq,32], lse [B,h,nq] (fused; scores never hit HBM)."""
+    _chk(q, k, v)
+    B, nq, D = q.shape
+    nk = k.shape[1]
+    o = empty(B, heads, nq, D // heads, like=q)
+    lse = empty(B, heads, nq, like=q)
+    check(_lib.lib().bdetr_attention_fwd(_p(q), _p(k), _p(v), _p(o), _p(lse), B, heads, nq, nk, scale, _stream()), "attention_fwd")
+    return o, lse
+
+
+def attention_bwd(q, k, v, o, d_o, lse, heads, scale):
+    _chk(q, k, v, o, d_o, lse)
+    B, nq, D = q.shape
+    nk = k.shape[1]
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    ws = empty(B * heads * nq, like=q)
+    check(_lib.lib().bdetr_attention_bwd(_p(q), _p(k), _p(v), _p(o), _p(d_o), _p(lse), _p(dq), _p(dk), _p(dv), _p(ws), B, heads, nq, nk,
+                                         scale, _stream()), "attention_bwd")
+    return dq, dk, dv
+
+
 def softmax_rows_fwd(s2d, scale=1.0, out=None):
     _chk(s2d, out)
     rows, cols = s2d.shape

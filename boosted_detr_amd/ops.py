@@ -351,6 +351,15 @@ def attention_core(Q: torch.Tensor, Kt: torch.Tensor, V: torch.Tensor, heads: in
     kk = Kt.shape[1]
     d = D // heads
     scale = 1.0 / math.sqrt(float(d))
+    if d == 32 and FUSED_ATTENTION[0]:
+        O, lse = K.attention_fwd(Q, Kt, V, heads, scale)
+
+        def backward_fused(gO):
+            dQ, dK, dV = K.attention_bwd(Q, Kt, V, O, gO.contiguous(), lse, heads, scale)
+            return _own(dQ), _own(dK), _own(dV)
+
+        _rec([O], [Q, Kt, V], backward_fused)
+        return O
     S = K.empty(B, heads, q, kk, like=Q)
     K.gemm_raw(q, kk, d, Q, D, True, Kt, D, True, S, kk, nb0=B, nb1=heads, sa=(q * D, d), sb=(kk * D, d), sc=(heads * q * kk, q * kk))
     P = K.softmax_rows_fwd(S.view(-1, kk), scale, out=S.view(-1, kk)).view(B, heads, q, kk)   # in place; Rescaling is fused
@@ -376,6 +385,9 @@ def attention_core(Q: torch.Tensor, Kt: torch.Tensor, V: torch.Tensor, heads: in
 
     _rec([O], [Q, Kt, V], backward)
     return O
+
+
+FUSED_ATTENTION = [True]     # head dim 32 -> csrc/attention.hip; other widths use batched GEMMs + softmax
 
 
 def add_dropout_layernorm(x: torch.Tensor, y: torch.Tensor, gamma: Variable, beta: Variable, eps: float, rate: float,

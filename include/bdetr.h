@@ -158,6 +158,18 @@ int bdetr_maxpool3x3s2_bwd(const float* x, const float* y, const float* dy, floa
 int bdetr_softmax_rows_fwd(const float* s, float* p, int64_t rows, int cols, float scale, void* stream);
 int bdetr_softmax_rows_bwd(const float* p, const float* dp, float* ds, int64_t rows, int cols, float scale, void* stream);
 
+/* Fused attention core for head dimension bdetr_attention_head_dim() (= 32): the [B,h,q,k] scores
+ * never reach HBM (online softmax in registers, K/V streamed through LDS, fp32 MFMA).
+ *   q [B,nq,h*32], k/v [B,nk,h*32]  ->  o [B,h,nq,32] (the layout transformers.py:100 reshapes
+ *   without a permute), lse [B,h,nq] = log-sum-exp of the scaled scores (kept for the backward).
+ *   bwd: dq [B,nq,h*32], dk/dv [B,nk,h*32]; dvec_ws: B*h*nq floats of workspace. */
+int bdetr_attention_head_dim(void);
+int bdetr_attention_fwd(const float* q, const float* k, const float* v, float* o, float* lse,
+                        int B, int h, int nq, int nk, float scale, void* stream);
+int bdetr_attention_bwd(const float* q, const float* k, const float* v, const float* o, const float* d_o,
+                        const float* lse, float* dq, float* dk, float* dv, float* dvec_ws,
+                        int B, int h, int nq, int nk, float scale, void* stream);
+
 /* ------------------------------------------------------------------------
  * K8  residual + dropout + LayerNormalization (transformers.py:135-137,178-180)
  *     h = x + dropout(y) ; out = gamma*(h-mean)*rstd + beta   (eps 1e-3, biased var)
