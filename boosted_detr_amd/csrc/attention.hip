@@ -26,15 +26,27 @@ constexpr int COLS_PER_BLOCK = 128;
 
 __device__ __forceinline__ int crow(int e, int lh) { return (e & 3) + 8 * (e >> 2) + 4 * lh; }   // accumulator row of register e
 
-// rows [r0, r0+64) of a strided matrix -> LDS [64][ALD]; rows >= n are zero-filled
-__device__ __forceinline__ void load_chunk(float* __restrict__ lds, const float* __restrict__ base, int64_t stride, int r0, int n) {
+// rows [r0, r0+64) of a strided matrix -> two float4 per thread (rows >= n are zero-filled) -> LDS [64][ALD].
+// Split in two so that the next chunk's HBM loads are in flight while the current chunk is computed.
+struct ChunkRegs { f32x4 v[2]; };
+__device__ __forceinline__ ChunkRegs fetch_chunk(const float* __restrict__ base, int64_t stride, int r0, int n) {
+    ChunkRegs c;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         const int v = threadIdx.x + 256 * p;
         const int row = v >> 3, c4 = v & 7;
-        f32x4 val = {0.f, 0.f, 0.f, 0.f};
-        if (r0 + row < n) val = *reinterpret_cast<const f32x4*>(base + (int64_t)(r0 + row) * stride + 4 * c4);
-        *reinterpret_cast<f32x4*>(lds + row * ALD + 4 * c4) = val;
+        const int rr = min(r0 + row, n - 1);                               // clamped address, value masked below: no branch around the load
+        f32x4 val = *reinterpret_cast<const f32x4*>(base + (int64_t)rr * stride + 4 * c4);
+        if (r0 + row >= n) val = f32x4{0.f, 0.f, 0.f, 0.f};
+        c.v[p] = val;
+    }
+    return c;
+}
+__device__ __forceinline__ void store_chunk(float* __restrict__ lds, const ChunkRegs& c) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int v = threadIdx.x + 256 * p;
+        *reinterpret_cast<f32x4*>(lds + (v >> 3) * ALD + 4 * (v & 7)) = c.v[p];
     }
 }
 
@@ -91,11 +103,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     for (int e = 0; e < 16; ++e) oacc[e] = 0.f;
     float m = -INFINITY, l = 0.f;
 
+    const bool wave_active = blockIdx.x * COLS_PER_BLOCK + wave * 32 < nq;      // wave-uniform: idle waves only help loading
+    ChunkRegs ck = fetch_chunk(kbase, D, 0, nk), cv = fetch_chunk(vbase, D, 0, nk);
     for (int c0 = 0; c0 < nk; c0 += CH) {
         __syncthreads();
-        load_chunk(sK, kbase, D, c0, nk);
-        load_chunk(sV, vbase, D, c0, nk);
+        store_chunk(sK, ck);
+        store_chunk(sV, cv);
         __syncthreads();
+        if (c0 + CH < nk) { ck = fetch_chunk(kbase, D, c0 + CH, nk); cv = fetch_chunk(vbase, D, c0 + CH, nk); }
+        if (!wave_active) continue;
         f32x16 s[2];
         float cmax = -INFINITY;
 #pragma unroll
@@ -183,16 +199,20 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
 #pragma unroll
     for (int e = 0; e < 16; ++e) { acc1[e] = 0.f; acc2[e] = 0.f; }
 
+    const bool wave_active = blockIdx.x * COLS_PER_BLOCK + wave * 32 < ncol;
+    ChunkRegs c1 = fetch_chunk(r1base, D, 0, nrow), c2 = fetch_chunk(r2base, r2stride, 0, nrow);
     for (int c0 = 0; c0 < nrow; c0 += CH) {
         __syncthreads();
-        load_chunk(sR1, r1base, D, c0, nrow);
-        load_chunk(sR2, r2base, r2stride, c0, nrow);
+        store_chunk(sR1, c1);
+        store_chunk(sR2, c2);
         if (KCOL && threadIdx.x < CH) {
             const int qi = c0 + threadIdx.x;
             sL[threadIdx.x] = qi < nq ? lse[bh * nq + qi] : 0.f;
             sD[threadIdx.x] = qi < nq ? dvec[bh * nq + qi] : 0.f;
         }
         __syncthreads();
+        if (c0 + CH < nrow) { c1 = fetch_chunk(r1base, D, c0 + CH, nrow); c2 = fetch_chunk(r2base, r2stride, c0 + CH, nrow); }
+        if (!wave_active) continue;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             f32x16 S = row_times_col(sR1, t, c1r, li, lh);      // scores      (rows = streamed side)
