@@ -166,12 +166,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
-    torch.cuda.set_device(local_rank)
+    # BDETR_FORCE_DEVICE / BDETR_DIST_BACKEND exist only to rehearse the N>1 code path on a one-GPU box
+    # (two ranks sharing cuda:0 over gloo); the driver's runs use one GPU per rank over RCCL ("nccl").
+    dev_index = int(os.environ.get("BDETR_FORCE_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("BDETR_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from boosted_detr_amd import _lib
     from boosted_detr_amd.engine import to_device
