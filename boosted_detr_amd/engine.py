@@ -255,11 +255,13 @@ class on_side_stream:
             t.record_stream(self.side)
         self.ctx = torch.cuda.stream(self.side)
         self.ctx.__enter__()
+        self.prev_handle = K.set_launch_stream(self.side.cuda_stream if K._LAUNCH_STREAM[0] is not None else None)
         _SIDE["used"] = True
         return self
 
     def __exit__(self, *exc):
         if self.side is not None:
+            K.set_launch_stream(self.prev_handle)
             self.ctx.__exit__(*exc)
         return False
 

@@ -18,8 +18,21 @@ from ._lib import ConvDesc, GemmDesc, LossDesc, check
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 
 
+# Raw hipStream_t the kernels are launched on.  Asking torch for the current stream costs ~8 us per
+# launch (a third of the host's enqueue time at ~1500 launches per step), so the training step pins
+# the handle for its duration (engine.on_side_stream swaps it while side-stream work is queued).
+_LAUNCH_STREAM = [None]
+
+
+def set_launch_stream(handle: Optional[int]) -> Optional[int]:
+    prev = _LAUNCH_STREAM[0]
+    _LAUNCH_STREAM[0] = handle
+    return prev
+
+
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    h = _LAUNCH_STREAM[0]
+    return h if h is not None else torch.cuda.current_stream().cuda_stream
 
 
 def _p(t: Optional[torch.Tensor]) -> Optional[int]:

@@ -251,9 +251,13 @@ class Model(Layer):
         if self.optimizer is not None and getattr(self.optimizer, "flat_grad", None) is not None:
             self.optimizer.flat_grad.zero_()     # ONE memset for all gradients (split-K GEMMs accumulate into zeros)
         tape = Tape()
-        with recording(tape):
-            y_pred = self(data, training=True)
-        tape.backward({id(t): t for t in self._loss_roots})     # parameter gradients land in Variable.grad (ops.GradSink)
+        prev = K.set_launch_stream(torch.cuda.current_stream().cuda_stream)     # pin the launch stream for the step
+        try:
+            with recording(tape):
+                y_pred = self(data, training=True)
+            tape.backward({id(t): t for t in self._loss_roots})     # parameter gradients land in Variable.grad (ops.GradSink)
+        finally:
+            K.set_launch_stream(prev)
         join_side_stream()                                      # weight-gradient GEMMs ran on the side stream
         return y_pred
 

@@ -1,8 +1,9 @@
+"""Host enqueue time vs GPU time of one training step (is the step GPU-bound?)."""
 import sys, time, torch
 sys.path.insert(0,'.')
 import bench
 class A: pass
-a=A(); a.queries=100; a.image=640; a.layers=6; a.batch=16
+a=A(); a.queries=100; a.image=640; a.layers=6; a.batch=16; a.model='detr'; a.fashionpedia=False; a.image_w=0; a.learners=3; a.backbone='ResNet'
 from boosted_detr_amd.engine import to_device
 m=bench.build_model(a)
 host=bench.make_batch(16,640,640,100,82,1234)
