@@ -61,9 +61,9 @@ class MatchingMask(Layer):
     def __call__(self, inputs, **kw):
         matching_costs, num_objects = inputs
         match = self.MatchingAssignment(matching_costs, num_objects)
-        mask = MatchingAssignment.mask(match, matching_costs.shape[-1])
-        assigned = mask.amax(dim=-2).unsqueeze(-1) if False else None    # not needed on device: set_loss derives it
-        return mask, match
+        # the reference also returns `assigned_predictions` (max of the mask over objects, 206-207); the
+        # loss kernel derives it from the match vector, so only the mask and the vector are returned
+        return MatchingAssignment.mask(match, matching_costs.shape[-1]), match
 
 
 class MatchingLoss(Layer):

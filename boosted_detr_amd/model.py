@@ -72,7 +72,7 @@ class DETR(Model):
                                                        attribute_weight=attribute_weight, exist_weight=exist_weight, name="MatchingLoss")
 
     def get_config(self):
-        c = super().get_config()
+        c = Model.get_config(self)            # explicit base: BoostedDETR reuses this function
         c.update({k: getattr(self, k) for k in ("num_object_preds", "image_size", "num_encoder_blocks", "num_encoder_heads", "encoder_dim",
                                                  "num_decoder_blocks", "num_decoder_heads", "decoder_dim", "num_panoptic_heads",
                                                  "panoptic_dim", "vocab_dict")})
