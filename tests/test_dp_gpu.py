@@ -1,0 +1,72 @@
+"""SURVEY 8(e) equivalence test: an R-replica data-parallel step (one process per replica,
+torch.distributed all-reduce of the flat gradient buffer, per-replica matcher / normaliser / BN, loss
+scaled by 1/R) reproduces (1/R) * sum_r grad(sum_{b in replica r} loss_b) computed by the CPU oracle,
+with BN in inference mode and dropout off.  Two ranks share the box's single GPU over gloo (the real
+runs use one GPU per rank over RCCL; the collective call sites are identical)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_WORKER = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+from test_training_gpu import small_model, small_batch
+from boosted_detr_amd.training import SGD
+from oracle import detr_oracle as O
+cfg, _ = small_batch()
+params = O.make_params(cfg, seed=2)
+full = O.make_batch(cfg, 4, 5, seed=21, num_objects=[2, 4, 1, 3])
+mine = {k: v[2 * rank: 2 * rank + 2] for k, v in full.items()}
+model = small_model()
+model.compile(optimizer=SGD(1e-3, momentum=.9, nesterov=True, clipnorm=.1))
+model.forward_backward(mine)
+model.set_weights_dict(params)
+for layer in (model.EncoderBackbone, model.BackboneNeck, model.CategoryPredictionHead, model.AttributePredictionHead, model.BoxPredictionHead):
+    layer.trainable = False                              # inference-mode BN everywhere (S18)
+model.distribute()
+assert abs(model.loss_fn.loss_scale - 1.0 / world) < 1e-12
+model._dp.broadcast_variables(model.variables)
+model.forward_backward(mine)
+tv = model.trainable_variables
+model.optimizer.stage_gradients(tv)
+model._dp.allreduce_(model.optimizer.flat_grad)
+torch.cuda.synchronize()
+if rank == 0:
+    want = {}
+    for r in range(world):
+        part = {k: v[2 * r: 2 * r + 2] for k, v in full.items()}
+        _, g = O.train_step_grads(cfg, params, part, dtype=torch.float64, frozen_bn=True, loss_scale=1.0 / world)
+        for k, v in g.items():
+            want[k] = want.get(k, 0) + v.astype(np.float64)
+    worst = 0.0
+    for v in tv:
+        w = want[v.name]
+        if np.abs(w).max() < 1e-9:
+            continue
+        err = np.linalg.norm(v.grad_numpy().astype(np.float64) - w) / np.linalg.norm(w)
+        worst = max(worst, err)
+        assert err < 2e-2, (v.name, err)
+    print("DP_EQUIVALENCE_OK worst_rel_l2=%.3e tensors=%d" % (worst, len(tv)))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_two_replica_gradient_equivalence(cuda, tmp_path):
+    script = tmp_path / "dp_worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
+    assert "DP_EQUIVALENCE_OK" in outs[0], outs[0][-2000:]
