@@ -52,6 +52,8 @@ SIGNATURES = {
     "bdetr_prof_read": (I, [P, P, P]),
     "bdetr_prof_dump": (I, [C.c_char_p]),
     "bdetr_image_prep": (I, [P, I, I, I, P, I, I, P]),
+    "bdetr_augment_ws_floats": (I, [I]),
+    "bdetr_augment": (I, [P, P, P, P, I, I, I, P, P]),
     "bdetr_conv2d_fwd": (I, [P, P, P, P, C.POINTER(ConvDesc), I, P, P, P]),
     "bdetr_conv2d_fwd_stat_chunks": (I, [C.POINTER(ConvDesc)]),
     "bdetr_conv2d_bwd_data": (I, [P, P, P, C.POINTER(ConvDesc), I, P]),

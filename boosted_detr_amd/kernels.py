@@ -70,6 +70,19 @@ def image_prep(image: torch.Tensor, H: int, W: int) -> torch.Tensor:
     return out
 
 
+def augment(image: torch.Tensor, iparams: torch.Tensor, fparams: torch.Tensor) -> torch.Tensor:
+    """pipeline.py:274-341 on the GPU.  image [B,H,W,3]; iparams int32 [B,4]; fparams f32 [B,3]."""
+    _chk(image, fparams)
+    _chk(iparams, dtype=torch.int32)
+    B, H, W, c = image.shape
+    assert c == 3
+    L = _lib.lib()
+    out = torch.empty_like(image)
+    ws = empty(L.bdetr_augment_ws_floats(B), like=image)
+    check(L.bdetr_augment(_p(image), _p(out), _p(iparams), _p(fparams), B, H, W, _p(ws), _stream()), "augment")
+    return out
+
+
 # --------------------------------------------------------------------------------------
 # convolution family
 # --------------------------------------------------------------------------------------

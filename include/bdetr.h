@@ -53,6 +53,15 @@ enum { BDETR_ACT_NONE = 0, BDETR_ACT_RELU = 1, BDETR_ACT_TANH = 2 };
  * ---------------------------------------------------------------------- */
 int bdetr_image_prep(const float* in, int B, int h, int w, float* out, int H, int W, void* stream);
 
+/* Input-step augmentations (pipeline.py:274-341): per image, bilinear down-size to
+ * (new_h,new_w), place at (off_h,off_w) on a zero canvas of the original size, then tf.image
+ * adjust_contrast / adjust_brightness / adjust_saturation with the given factors.  in/out: [B,H,W,3]
+ * (out != in); iparams int32 [B][4] = new_h,new_w,off_h,off_w; fparams [B][3] = contrast, brightness
+ * delta, saturation; ws: bdetr_augment_ws_floats(B) floats.  The random draws are the host's. */
+int bdetr_augment_ws_floats(int B);
+int bdetr_augment(const float* in, float* out, const int32_t* iparams, const float* fparams,
+                  int B, int H, int W, float* ws, void* stream);
+
 /* ------------------------------------------------------------------------
  * K2/K5/K6  MFMA implicit-GEMM family (v_mfma_f32_32x32x2_f32, LDS-staged tiles).
  * ---------------------------------------------------------------------- */
