@@ -28,6 +28,7 @@ class GemmDesc(C.Structure):
         ("b", C.c_void_p), ("ldb", C.c_int64), ("sb0", C.c_int64), ("sb1", C.c_int64), ("b_rcontig", C.c_int),
         ("c", C.c_void_p), ("ldc", C.c_int64), ("sc0", C.c_int64), ("sc1", C.c_int64),
         ("bias", C.c_void_p), ("alpha", C.c_float), ("act", C.c_int), ("accumulate", C.c_int), ("splitk", C.c_int),
+        ("grad", C.c_int),
     ]
 
 
@@ -48,6 +49,8 @@ SIGNATURES = {
     "bdetr_abi_version": (I, []),
     "bdetr_last_error": (C.c_char_p, []),
     "bdetr_device_cus": (I, []),
+    "bdetr_set_gemm_precision": (I, [I]),
+    "bdetr_get_gemm_precision": (I, []),
     "bdetr_prof_enable": (I, [I]),
     "bdetr_prof_read": (I, [P, P, P]),
     "bdetr_prof_dump": (I, [C.c_char_p]),
@@ -124,7 +127,7 @@ def lib():
         fn = getattr(h, name)          # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if h.bdetr_abi_version() != 1:
+    if h.bdetr_abi_version() != 2:
         raise BdetrError("libbdetr.so ABI version mismatch; rebuild")
     _lib = h
     return _lib

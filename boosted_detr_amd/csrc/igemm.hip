@@ -15,6 +15,7 @@
 //  prediction_heads.py:40-43,106-110,175-179).
 #include "common.h"
 #include <stdlib.h>
+#include <string.h>
 #include <utility>
 #include <vector>
 
@@ -23,6 +24,28 @@ namespace {
 constexpr int BK = 32;       // r-depth of one LDS stage
 constexpr int RPAD = 4;      // row padding (floats) of r-contiguous LDS tiles: conflict-free ds_read_b128
 constexpr int NTHREADS = 256;
+
+// Split-bf16 ("bf16x3") mode: every fp32 operand value x is staged in LDS as two bf16 numbers
+// hi = bf16(x) and lo = bf16(x - hi), and a product is evaluated as hi*hi + hi*lo + lo*hi on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation: ~2^-17 relative error per product (between fp32's
+// 2^-24 and the TF32 2^-11 the reference's TensorFlow uses on tensor-core GPUs) at 3/16 of the fp32
+// MFMA's cycles.  LDS rows are k-contiguous for both operand flavours (the MFMA wants 8 consecutive
+// k per lane): [x][16 dwords hi | 16 dwords lo | 4 pad], one dword = the k-pair (2t, 2t+1); the
+// 16-byte chunks of a row are XOR-swizzled with (x >> 4) & 7 so that both the ds_read_b128 fragment
+// reads and the transposing ds_write_b32 of x-contiguous operands are bank-conflict free.
+constexpr int SLD = 36;      // dwords per LDS row in split mode
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigned& lo) {
+    f32x2 v; v[0] = x0; v[1] = x1;
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));        // v_cvt_pk_bf16_f32 (RNE)
+    f32x2 r;
+    r[0] = x0 - __builtin_bit_cast(float, hi << 16);                              // exact in fp32
+    r[1] = x1 - __builtin_bit_cast(float, hi & 0xFFFF0000u);
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+}
 
 // ----------------------------------------------------------------------------------------
 // operand descriptors + loaders
@@ -36,6 +59,7 @@ struct WFlipOp { const float* p; int K, C, R, S; int rows, cols; };
 // tails, so the staging loads carry no control flow and stay in flight under the MFMA block (with
 // branchy zero-fill code hipcc placed s_waitcnt vmcnt(0) in FRONT of the MFMAs).
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 constexpr unsigned OOB = 0xFFFFFFF0u;              // byte offset beyond num_records -> load returns 0
 constexpr unsigned NUM_RECORDS = 0xFFFFFF00u;      // operands must span < 4 GB (checked on the host)
 
@@ -155,7 +179,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return v;
 }
 
-template <int BM, int BN, int WM, int WN, class LA, bool A_RC, class LB, bool B_RC>
+template <int BM, int BN, int WM, int WN, class LA, bool A_RC, class LB, bool B_RC, bool SPLIT>
 __global__ __launch_bounds__(NTHREADS, 2)
 void igemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
 {
@@ -167,8 +191,11 @@ void igemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
     using GB = TileGeom<BN, B_RC>;
     static_assert(GA::NV >= 1 && GB::NV >= 1, "tile too small for 256 threads");
 
-    __shared__ __attribute__((aligned(16))) float lds[2 * (GA::LDS_FLOATS + GB::LDS_FLOATS)];
-    constexpr int STAGE_FLOATS = GA::LDS_FLOATS + GB::LDS_FLOATS;
+    constexpr int A_FLOATS = SPLIT ? BM * SLD : GA::LDS_FLOATS;
+    constexpr int B_FLOATS = SPLIT ? BN * SLD : GB::LDS_FLOATS;
+    constexpr int STAGE_FLOATS = A_FLOATS + B_FLOATS;
+    static_assert(!SPLIT || ((A_RC || GA::NV % 2 == 0) && (B_RC || GB::NV % 2 == 0)), "split mode transposes k-pairs");
+    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE_FLOATS];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -218,19 +245,35 @@ void igemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
     typename LA::Ctx ctxA[GA::NV];
     typename LB::Ctx ctxB[GB::NV];
     int colA[GA::NV], colB[GB::NV], ldsoffA[GA::NV], ldsoffB[GB::NV], rowA[GA::NV], rowB[GB::NV];
+    // split mode: ldsoff = (row base in dwords) * 32 + (swizzled dword inside the row's hi half); the lo
+    // half is the same position with bit 4 flipped.  x-contiguous operands are loaded as k-row pairs
+    // (p even: row 2t, p odd: row 2t+1, same 4 x columns) so that a thread can pack k-pairs itself.
+    auto stage_geom = [&](int p, int vpr, int bx, bool rc, int lds_ld, int& row, int& col, int& ldsoff) {
+        if (!SPLIT) {
+            const int v = tid + NTHREADS * p;
+            const int rt = v / vpr, c4 = v - rt * vpr;
+            row = rt; col = 4 * c4; ldsoff = rt * lds_ld + 4 * c4;
+        } else if (rc) {
+            const int v = tid + NTHREADS * p;
+            const int rt = v / vpr, c4 = v - rt * vpr;           // vpr = 8: k = 4*c4 .. 4*c4+3
+            row = rt; col = 4 * c4;
+            ldsoff = rt * SLD * 32 + ((((c4 >> 1) ^ ((rt >> 4) & 7)) << 2) | ((c4 & 1) << 1));
+        } else {
+            const int u = tid + NTHREADS * (p >> 1);
+            const int kp = u / (bx / 4), c4 = u - kp * (bx / 4);
+            row = 2 * kp + (p & 1); col = 4 * c4;
+            ldsoff = (4 * c4) * SLD * 32 + ((((kp >> 2) ^ ((c4 >> 2) & 7)) << 2) | (kp & 3));
+        }
+    };
 #pragma unroll
     for (int p = 0; p < GA::NV; ++p) {
-        int v = tid + NTHREADS * p;
-        int rt = v / GA::VPR, c4 = v - rt * GA::VPR;
-        rowA[p] = rt; colA[p] = 4 * c4; ldsoffA[p] = rt * GA::LDS_LD + 4 * c4;
-        if (A_RC) ctxA[p] = LA::row_ctx(opa, i0 + rt, a_rows);
+        stage_geom(p, GA::VPR, BM, A_RC, GA::LDS_LD, rowA[p], colA[p], ldsoffA[p]);
+        if (A_RC) ctxA[p] = LA::row_ctx(opa, i0 + rowA[p], a_rows);
     }
 #pragma unroll
     for (int p = 0; p < GB::NV; ++p) {
-        int v = tid + NTHREADS * p;
-        int rt = v / GB::VPR, c4 = v - rt * GB::VPR;
-        rowB[p] = rt; colB[p] = 4 * c4; ldsoffB[p] = rt * GB::LDS_LD + 4 * c4;
-        if (B_RC) ctxB[p] = LB::row_ctx(opb, j0 + rt, b_rows);
+        stage_geom(p, GB::VPR, BN, B_RC, GB::LDS_LD, rowB[p], colB[p], ldsoffB[p]);
+        if (B_RC) ctxB[p] = LB::row_ctx(opb, j0 + rowB[p], b_rows);
     }
 
     // Two register staging sets: the loads of K-step t+2 are issued while K-step t computes, so an
@@ -248,7 +291,42 @@ void igemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
             else      rb[p] = LB::load(rsB, opb, LB::row_ctx(opb, r0 + rowB[p], b_rows), j0 + colB[p], b_cols);
         }
     };
+    auto write_split = [&](unsigned* base, bool rc, int nv, const f32x4* r, const int* ldsoff) {
+        if (rc) {
+#pragma unroll
+            for (int p = 0; p < nv; ++p) {
+                unsigned h0, l0, h1, l1;
+                split2(r[p][0], r[p][1], h0, l0);
+                split2(r[p][2], r[p][3], h1, l1);
+                u32x2 hi, lo;
+                hi[0] = h0; hi[1] = h1; lo[0] = l0; lo[1] = l1;
+                unsigned* row = base + (ldsoff[p] >> 5);
+                const int w = ldsoff[p] & 31;
+                *reinterpret_cast<u32x2*>(row + w) = hi;
+                *reinterpret_cast<u32x2*>(row + (w ^ 16)) = lo;
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p + 1 < nv; p += 2) {
+                unsigned* row = base + (ldsoff[p] >> 5);
+                const int w = ldsoff[p] & 31;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    unsigned hi, lo;
+                    split2(r[p][e], r[p + 1][e], hi, lo);
+                    row[e * SLD + w] = hi;
+                    row[e * SLD + (w ^ 16)] = lo;
+                }
+            }
+        }
+    };
     auto write_stage = [&](int buf, const f32x4 (&ra)[GA::NV], const f32x4 (&rb)[GB::NV]) {
+        if (SPLIT) {
+            unsigned* st = reinterpret_cast<unsigned*>(lds + buf * STAGE_FLOATS);
+            write_split(st, A_RC, GA::NV, ra, ldsoffA);
+            write_split(st + A_FLOATS, B_RC, GB::NV, rb, ldsoffB);
+            return;
+        }
 #pragma unroll
         for (int p = 0; p < GA::NV; ++p) *reinterpret_cast<f32x4*>(lds + buf * STAGE_FLOATS + ldsoffA[p]) = ra[p];
 #pragma unroll
@@ -264,6 +342,37 @@ void igemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
     auto compute = [&](int buf) {
+        if (SPLIT) {
+            const unsigned* qA = reinterpret_cast<const unsigned*>(lds + buf * STAGE_FLOATS);
+            const unsigned* qB = qA + A_FLOATS;
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+                for (int a = 0; a < TM; ++a) {
+                    const int xb = wm * WTM + a * 32 + li;
+                    const int w = ((ks * 2 + lh) ^ ((xb >> 4) & 7)) << 2;
+                    ah[a] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qA + xb * SLD + w));
+                    al[a] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qA + xb * SLD + (w ^ 16)));
+                }
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    const int xb = wn * WTN + b * 32 + li;
+                    const int w = ((ks * 2 + lh) ^ ((xb >> 4) & 7)) << 2;
+                    bh[b] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qB + xb * SLD + w));
+                    bl[b] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qB + xb * SLD + (w ^ 16)));
+                }
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) {
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+                    }
+            }
+            return;
+        }
         const float* sA = lds + buf * STAGE_FLOATS;
         const float* sB = sA + GA::LDS_FLOATS;
 #pragma unroll
@@ -300,6 +409,17 @@ void igemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
     };
 
     const int nk = (r_end - r_begin + BK - 1) / BK;
+    constexpr bool PF1 = SPLIT && BM * BN >= 128 * 128;     // one staging set (register budget of the widest tile)
+    if constexpr (PF1) {
+        if (nk > 0) { load_stage(r_begin, stA0, stB0); write_stage(0, stA0, stB0); }
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) load_stage(r_begin + (kt + 1) * BK, stA0, stB0);
+            compute(kt & 1);
+            if (kt + 1 < nk) write_stage((kt + 1) & 1, stA0, stB0);
+            __syncthreads();
+        }
+    } else {
     if (nk > 0) {
         load_stage(r_begin, stA0, stB0);
         if (nk > 1) load_stage(r_begin + BK, stA1, stB1);
@@ -319,6 +439,7 @@ void igemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
         compute(1);
         if (kt + 2 < nk) write_stage(0, stA0, stB0);
         __syncthreads();
+    }
     }
 
     // ---------------- epilogue ----------------
@@ -423,7 +544,20 @@ int num_cus() {
 
 // Pick the biggest tile that still gives every CU ~2 workgroups; small-J problems get narrow tiles.
 // BDETR_TILE=<bm>x<bn> (e.g. 128x64) forces a tile for tuning experiments.
-TileChoice choose_tile(int I, int J, int zdim) {
+// GEMM arithmetic policy (include/bdetr.h): BDETR_GEMM_PRECISION=fp32|bf16x3|mixed sets the initial value,
+// bdetr_set_gemm_precision() changes it at run time.  use_split(grad) answers for one product.
+int g_gemm_mode = -1;
+int gemm_mode() {
+    if (g_gemm_mode < 0) {
+        const char* e = getenv("BDETR_GEMM_PRECISION");
+        g_gemm_mode = !e ? BDETR_GEMM_MIXED : (!strcmp(e, "fp32") || !strcmp(e, "f32")) ? BDETR_GEMM_FP32
+                    : !strcmp(e, "bf16x3") ? BDETR_GEMM_BF16X3 : BDETR_GEMM_MIXED;
+    }
+    return g_gemm_mode;
+}
+bool use_split(bool grad) { const int m = gemm_mode(); return m == BDETR_GEMM_BF16X3 || (m == BDETR_GEMM_MIXED && grad); }
+
+TileChoice choose_tile(int I, int J, int zdim, bool both_rc, bool split) {
     static int forced_bm = -1, forced_bn = -1;
     if (forced_bm < 0) {
         forced_bm = forced_bn = 0;
@@ -438,12 +572,17 @@ TileChoice choose_tile(int I, int J, int zdim) {
     // N <= 2048): 97-108 vs 51-95 TF/s; 128x128 only wins once there are >= ~16 tiles per CU.
     auto tiles = [&](int bm, int bn) { return cdiv64(I, bm) * cdiv64(J, bn) * zdim; };
     if (J <= 32) return {128, 32};
+    if (split) {
+        // bf16x3 (tools/gemm_bench.py on MI355X): the per-element hi/lo split is VALU work that a wider tile
+        // amortises over more MFMAs, so 128x128 wins 10-25 % on the r-contiguous x r-contiguous flavour
+        // (conv/dense forward) once it still yields ~a workgroup per CU; the transposing flavours and the
+        // small problems stay on 64x64.
+        if (both_rc && J % 128 == 0 && tiles(128, 128) * 4 >= 3LL * num_cus()) return {128, 128};
+        return {64, 64};
+    }
     if (tiles(128, 128) >= 16LL * num_cus() && J >= 1024) return {128, 128};
     return {64, 64};
 }
-
-template <int BM, int BN, int WM, int WN, class LA, bool A_RC, class LB, bool B_RC>
-int launch_cfg(const typename LA::Op& a, const typename LB::Op& b, GemmParams g, int zdim, hipStream_t st);
 
 // ---- optional live profiling of the MFMA kernel family (bench.py's roofline leg) -----------------
 // When enabled, every igemm launch is bracketed by two hipEvents recorded on the launch stream; the
@@ -471,7 +610,7 @@ void prof_begin(hipStream_t st, double flops, int I, int J, int R, int z, int bm
 }
 void prof_end(hipStream_t st) { hipEventRecord(g_prof_recs.back().e1, st); }
 
-template <int BM, int BN, int WM, int WN, class LA, bool A_RC, class LB, bool B_RC>
+template <int BM, int BN, int WM, int WN, class LA, bool A_RC, class LB, bool B_RC, bool SPLIT = false>
 int launch_cfg(const typename LA::Op& a, const typename LB::Op& b, GemmParams g, int zdim, hipStream_t st) {
     g.tiles_i = (int)cdiv64(g.I, BM);
     g.tiles_j = (int)cdiv64(g.J, BN);
@@ -479,15 +618,23 @@ int launch_cfg(const typename LA::Op& a, const typename LB::Op& b, GemmParams g,
     g.vec_store = (g.J % 4 == 0) && (g.ldc % 4 == 0) && (g.sc0 % 4 == 0) && (g.sc1 % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.c) & 15) == 0);
     const bool prof = g_prof_on;
     if (prof) prof_begin(st, 2.0 * (double)g.I * (double)g.J * (double)g.R * (g.splitk > 1 ? 1.0 : (double)zdim), g.I, g.J, g.R, zdim, BM, BN,
-                         LoaderId<LA>::v * 1000 + (A_RC ? 100 : 0) + LoaderId<LB>::v * 10 + (B_RC ? 1 : 0));
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, LA, A_RC, LB, B_RC>), grid, dim3(NTHREADS), 0, st, a, b, g);
+                         (SPLIT ? 10000 : 0) + LoaderId<LA>::v * 1000 + (A_RC ? 100 : 0) + LoaderId<LB>::v * 10 + (B_RC ? 1 : 0));
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, LA, A_RC, LB, B_RC, SPLIT>), grid, dim3(NTHREADS), 0, st, a, b, g);
     if (prof) prof_end(st);
     return bdetr_launch_status("igemm");
 }
 
 template <class LA, bool A_RC, class LB, bool B_RC>
-int launch_any(const typename LA::Op& a, const typename LB::Op& b, GemmParams g, int zdim, hipStream_t st, bool small_only = false) {
-    TileChoice t = small_only ? TileChoice{64, 64} : choose_tile(g.I, g.J, zdim);
+int launch_any(const typename LA::Op& a, const typename LB::Op& b, GemmParams g, int zdim, hipStream_t st, bool split, bool small_only = false) {
+    TileChoice t = small_only ? TileChoice{64, 64} : choose_tile(g.I, g.J, zdim, A_RC && B_RC, split);
+    if constexpr (LoaderId<LA>::v != 3 && LoaderId<LB>::v != 3) {
+        // 16-byte loaders only; the narrow 128x32 tile (J <= 32: tiny heads) stays on the fp32 kernel
+        if (split && t.bn >= 64) {
+            if (t.bm == 128 && t.bn == 128) return launch_cfg<128, 128, 2, 2, LA, A_RC, LB, B_RC, true>(a, b, g, zdim, st);
+            if (t.bm == 128 && t.bn == 64)  return launch_cfg<128, 64, 2, 2, LA, A_RC, LB, B_RC, true>(a, b, g, zdim, st);
+            return launch_cfg<64, 64, 2, 2, LA, A_RC, LB, B_RC, true>(a, b, g, zdim, st);
+        }
+    }
     if (t.bm == 128 && t.bn == 128) return launch_cfg<128, 128, 2, 2, LA, A_RC, LB, B_RC>(a, b, g, zdim, st);
     if (t.bm == 128 && t.bn == 64)  return launch_cfg<128, 64, 2, 2, LA, A_RC, LB, B_RC>(a, b, g, zdim, st);
     if (t.bm == 128 && t.bn == 32)  return launch_cfg<128, 32, 4, 1, LA, A_RC, LB, B_RC>(a, b, g, zdim, st);
@@ -498,7 +645,7 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 
 // number of partial-statistics rows the epilogue writes for an (I,J) problem: tiles_i * WM
 int stat_chunks(int I, int J) {
-    TileChoice t = choose_tile(I, J, 1);
+    TileChoice t = choose_tile(I, J, 1, true, use_split(false));
     const int wm = (t.bm == 128 && t.bn == 32) ? 4 : 2;
     return (int)cdiv64(I, t.bm) * wm;
 }
@@ -514,6 +661,13 @@ void init_params(GemmParams& g) {
 // C ABI
 // ----------------------------------------------------------------------------------------
 extern "C" int bdetr_device_cus(void) { return num_cus(); }
+
+extern "C" int bdetr_set_gemm_precision(int mode) {
+    BDETR_CHECK_ARG(mode == BDETR_GEMM_FP32 || mode == BDETR_GEMM_BF16X3 || mode == BDETR_GEMM_MIXED, "bdetr_set_gemm_precision: unknown mode %d", mode);
+    g_gemm_mode = mode;
+    return 0;
+}
+extern "C" int bdetr_get_gemm_precision(void) { return gemm_mode(); }
 
 extern "C" int bdetr_prof_enable(int on) {
     g_prof_on = on != 0;
@@ -564,6 +718,7 @@ extern "C" int bdetr_gemm_grouped(const bdetr_gemm_desc* d, int n, void* stream)
                         e.act == d[0].act && e.alpha == d[0].alpha && e.accumulate == d[0].accumulate &&
                         e.lda == d[0].lda && e.ldb == d[0].ldb && e.ldc == d[0].ldc,
                         "bdetr_gemm_grouped: problems must share J, R, leading dimensions, flavours and epilogue");
+        BDETR_CHECK_ARG(e.grad == d[0].grad, "bdetr_gemm_grouped: problems must share the grad flag");
         BDETR_CHECK_ARG((e.nb0 <= 1) && (e.nb1 <= 1) && e.splitk <= 1, "bdetr_gemm_grouped: no batching / split-K inside a group");
         g.ga[k] = e.a; g.gb[k] = e.b; g.gc[k] = e.c; g.gbias[k] = e.bias; g.gI[k] = e.I;
         if (e.I > maxI) maxI = e.I;
@@ -580,10 +735,11 @@ extern "C" int bdetr_gemm_grouped(const bdetr_gemm_desc* d, int n, void* stream)
     DenseOp b{f.b, f.ldb, 0, 0, f.b_rcontig ? f.J : f.R, f.b_rcontig ? f.R : f.J};
     hipStream_t st = (hipStream_t)stream;
     const bool arc = f.a_rcontig != 0, brc = f.b_rcontig != 0;
-    if (arc && brc)   return launch_any<DenseLoader<4>, true, DenseLoader<4>, true>(a, b, g, n, st);
-    if (arc && !brc)  return launch_any<DenseLoader<4>, true, DenseLoader<4>, false>(a, b, g, n, st);
-    if (!arc && !brc) return launch_any<DenseLoader<4>, false, DenseLoader<4>, false>(a, b, g, n, st);
-    return launch_any<DenseLoader<4>, false, DenseLoader<4>, true>(a, b, g, n, st, true);
+    const bool sp = use_split(f.grad != 0);
+    if (arc && brc)   return launch_any<DenseLoader<4>, true, DenseLoader<4>, true>(a, b, g, n, st, sp);
+    if (arc && !brc)  return launch_any<DenseLoader<4>, true, DenseLoader<4>, false>(a, b, g, n, st, sp);
+    if (!arc && !brc) return launch_any<DenseLoader<4>, false, DenseLoader<4>, false>(a, b, g, n, st, sp);
+    return launch_any<DenseLoader<4>, false, DenseLoader<4>, true>(a, b, g, n, st, sp, true);
 }
 
 extern "C" int bdetr_gemm(const bdetr_gemm_desc* d, void* stream) {
@@ -613,17 +769,18 @@ extern "C" int bdetr_gemm(const bdetr_gemm_desc* d, void* stream) {
     };
     const bool v4 = vec_ok(a) && vec_ok(b);
     const bool arc = d->a_rcontig != 0, brc = d->b_rcontig != 0;
+    const bool sp = use_split(d->grad != 0);
     if (v4) {
-        if (arc && brc)   return launch_any<DenseLoader<4>, true, DenseLoader<4>, true>(a, b, g, zdim, st);
-        if (arc && !brc)  return launch_any<DenseLoader<4>, true, DenseLoader<4>, false>(a, b, g, zdim, st);
-        if (!arc && !brc) return launch_any<DenseLoader<4>, false, DenseLoader<4>, false>(a, b, g, zdim, st);
-        return launch_any<DenseLoader<4>, false, DenseLoader<4>, true>(a, b, g, zdim, st, true);
+        if (arc && brc)   return launch_any<DenseLoader<4>, true, DenseLoader<4>, true>(a, b, g, zdim, st, sp);
+        if (arc && !brc)  return launch_any<DenseLoader<4>, true, DenseLoader<4>, false>(a, b, g, zdim, st, sp);
+        if (!arc && !brc) return launch_any<DenseLoader<4>, false, DenseLoader<4>, false>(a, b, g, zdim, st, sp);
+        return launch_any<DenseLoader<4>, false, DenseLoader<4>, true>(a, b, g, zdim, st, sp, true);
     }
     // unaligned fallback (scalar HBM loads): only tiny problems take it (82-wide heads, T=49 attention)
-    if (arc && brc)   return launch_any<DenseLoader<1>, true, DenseLoader<1>, true>(a, b, g, zdim, st, true);
-    if (arc && !brc)  return launch_any<DenseLoader<1>, true, DenseLoader<1>, false>(a, b, g, zdim, st, true);
-    if (!arc && !brc) return launch_any<DenseLoader<1>, false, DenseLoader<1>, false>(a, b, g, zdim, st, true);
-    return launch_any<DenseLoader<1>, false, DenseLoader<1>, true>(a, b, g, zdim, st, true);
+    if (arc && brc)   return launch_any<DenseLoader<1>, true, DenseLoader<1>, true>(a, b, g, zdim, st, false, true);
+    if (arc && !brc)  return launch_any<DenseLoader<1>, true, DenseLoader<1>, false>(a, b, g, zdim, st, false, true);
+    if (!arc && !brc) return launch_any<DenseLoader<1>, false, DenseLoader<1>, false>(a, b, g, zdim, st, false, true);
+    return launch_any<DenseLoader<1>, false, DenseLoader<1>, true>(a, b, g, zdim, st, false, true);
 }
 
 static int check_conv(const bdetr_conv_desc* d, const char* who) {
@@ -657,10 +814,10 @@ extern "C" int bdetr_conv2d_fwd(const float* x, const float* w, const float* bia
     hipStream_t st = (hipStream_t)stream;
     if (d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0) {
         DenseOp xop{x, d->C, 0, 0, M, d->C};
-        return launch_any<DenseLoader<4>, true, DenseLoader<4>, true>(xop, wop, g, 1, st);
+        return launch_any<DenseLoader<4>, true, DenseLoader<4>, true>(xop, wop, g, 1, st, use_split(false));
     }
     PatchOp xop{x, d->N, d->H, d->W, d->C, d->OH, d->OW, d->R, d->S, d->stride, d->pad, M, Kd};
-    return launch_any<PatchLoader, true, DenseLoader<4>, true>(xop, wop, g, 1, st);
+    return launch_any<PatchLoader, true, DenseLoader<4>, true>(xop, wop, g, 1, st, use_split(false));
 }
 
 extern "C" int bdetr_conv2d_bwd_data(const float* dy, const float* w, float* dx,
@@ -684,7 +841,7 @@ extern "C" int bdetr_conv2d_bwd_data(const float* dy, const float* w, float* dx,
         }
         DenseOp a{dy, d->K, 0, 0, M, d->K};
         DenseOp b{w, d->C, 0, 0, d->K, d->C};
-        return launch_any<DenseLoader<4>, true, DenseLoader<4>, false>(a, b, g, 1, st);
+        return launch_any<DenseLoader<4>, true, DenseLoader<4>, false>(a, b, g, 1, st, use_split(true));
     }
     BDETR_CHECK_ARG(d->stride == 1, "bdetr_conv2d_bwd_data: stride>1 only for 1x1 convs");
     // dx[n,ih,iw,c] = sum_{r,s,k} dy[n, ih+pad-r, iw+pad-s, k] * w[k][r][s][c]
@@ -694,13 +851,13 @@ extern "C" int bdetr_conv2d_bwd_data(const float* dy, const float* w, float* dx,
     PatchOp a{dy, d->N, d->OH, d->OW, d->K, d->H, d->W, d->R, d->S, 1, d->R - 1 - d->pad, Mx, d->R * d->S * d->K};
     BDETR_CHECK_ARG(d->R == d->S, "bdetr_conv2d_bwd_data: square kernels only");
     WFlipOp b{w, d->K, d->C, d->R, d->S, d->R * d->S * d->K, d->C};
-    return launch_any<PatchLoader, true, WFlipLoader, false>(a, b, g, 1, st);
+    return launch_any<PatchLoader, true, WFlipLoader, false>(a, b, g, 1, st, use_split(true));
 }
 
 extern "C" int bdetr_conv2d_bwd_weight_splitk(const bdetr_conv_desc* d) {
     if (check_conv(d, "bdetr_conv2d_bwd_weight_splitk")) return -1;
     const int M = d->N * d->OH * d->OW, Kd = d->R * d->S * d->C;
-    TileChoice t = choose_tile(d->K, Kd, 1);
+    TileChoice t = choose_tile(d->K, Kd, 1, false, use_split(true));
     int64_t tiles = cdiv64(d->K, t.bm) * cdiv64(Kd, t.bn);
     int64_t want = 3LL * num_cus();
     int64_t sk = cdiv64(want, tiles);
@@ -732,8 +889,8 @@ extern "C" int bdetr_conv2d_bwd_weight(const float* x, const float* dy, float* d
     DenseOp a{dy, d->K, 0, 0, M, d->K};           // rows = r (pixels), cols = i (k)
     if (d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0) {
         DenseOp b{x, d->C, 0, 0, M, d->C};
-        return launch_any<DenseLoader<4>, false, DenseLoader<4>, false>(a, b, g, zdim, st);
+        return launch_any<DenseLoader<4>, false, DenseLoader<4>, false>(a, b, g, zdim, st, use_split(true));
     }
     PatchOp b{x, d->N, d->H, d->W, d->C, d->OH, d->OW, d->R, d->S, d->stride, d->pad, M, Kd};
-    return launch_any<DenseLoader<4>, false, PatchLoader, false>(a, b, g, zdim, st);
+    return launch_any<DenseLoader<4>, false, PatchLoader, false>(a, b, g, zdim, st, use_split(true));
 }

@@ -30,6 +30,24 @@ def set_launch_stream(handle: Optional[int]) -> Optional[int]:
     return prev
 
 
+GEMM_FP32, GEMM_BF16X3, GEMM_MIXED = 0, 1, 2
+_GEMM_MODES = {"fp32": GEMM_FP32, "bf16x3": GEMM_BF16X3, "mixed": GEMM_MIXED}
+
+
+def set_gemm_precision(mode) -> int:
+    """Arithmetic of the conv/GEMM family: 'fp32' (exact fp32 MFMA everywhere), 'bf16x3' (split-bf16
+    everywhere) or 'mixed' (default: exact forward, split-bf16 gradient products).  Returns the previous mode."""
+    code = _GEMM_MODES.get(mode, mode)
+    prev = _lib.lib().bdetr_get_gemm_precision()
+    check(_lib.lib().bdetr_set_gemm_precision(int(code)), "set_gemm_precision")
+    return prev
+
+
+def get_gemm_precision() -> str:
+    code = _lib.lib().bdetr_get_gemm_precision()
+    return next(k for k, v in _GEMM_MODES.items() if v == code)
+
+
 def _stream() -> int:
     h = _LAUNCH_STREAM[0]
     return h if h is not None else torch.cuda.current_stream().cuda_stream
@@ -162,21 +180,22 @@ def conv2d_bwd_weight(x, dy, g: ConvGeom, dw: Optional[torch.Tensor] = None, pre
 # GEMM
 # --------------------------------------------------------------------------------------
 def gemm_raw(I, J, R, a, lda, a_rc, b, ldb, b_rc, c, ldc, *, nb0=1, nb1=1, sa=(0, 0), sb=(0, 0), sc=(0, 0),
-             bias=None, alpha=1.0, act=ACT_NONE, accumulate=False, splitk=1):
+             bias=None, alpha=1.0, act=ACT_NONE, accumulate=False, splitk=1, grad=False):
     _chk(a, b, c, bias)
     g = GemmDesc(I, J, R, nb0, nb1, _p(a), lda, sa[0], sa[1], int(a_rc), _p(b), ldb, sb[0], sb[1], int(b_rc),
-                 _p(c), ldc, sc[0], sc[1], _p(bias), float(alpha), act, int(accumulate), splitk)
+                 _p(c), ldc, sc[0], sc[1], _p(bias), float(alpha), act, int(accumulate), splitk, int(grad))
     check(_lib.lib().bdetr_gemm(C.byref(g), _stream()), "gemm")
     return c
 
 
 def gemm_grouped(descs):
-    """descs: list of (I, J, R, a, lda, a_rc, b, ldb, b_rc, c, ldc, bias, act, accumulate)."""
+    """descs: list of (I, J, R, a, lda, a_rc, b, ldb, b_rc, c, ldc, bias, act, accumulate); a product with an
+    x-contiguous operand is a gradient product (dy @ w)."""
     arr = (GemmDesc * len(descs))()
     for k, (I, J, R, a, lda, a_rc, b, ldb, b_rc, c, ldc, bias, act, acc) in enumerate(descs):
         _chk(a, b, c, bias)
         arr[k] = GemmDesc(I, J, R, 1, 1, _p(a), lda, 0, 0, int(a_rc), _p(b), ldb, 0, 0, int(b_rc), _p(c), ldc, 0, 0, _p(bias), 1.0, act,
-                          int(acc), 1)
+                          int(acc), 1, int(not (a_rc and b_rc)))
     check(_lib.lib().bdetr_gemm_grouped(arr, len(descs), _stream()), "gemm_grouped")
 
 
@@ -210,7 +229,7 @@ def linear_bwd_data(dy2d, w, dx=None, accumulate=False):
     K = w.shape[1]
     if dx is None:
         dx = empty(M, K, like=dy2d)
-    return gemm_raw(M, K, O, dy2d, O, True, w, K, False, dx, K, accumulate=accumulate)
+    return gemm_raw(M, K, O, dy2d, O, True, w, K, False, dx, K, accumulate=accumulate, grad=True)
 
 
 def _auto_splitk(I, J, R) -> int:
@@ -230,7 +249,7 @@ def linear_bwd_weight(dy2d, x2d, dw=None, prezeroed: bool = False):
     sk = _auto_splitk(O, K, M)
     if sk > 1 and not prezeroed:
         check(_lib.lib().bdetr_zero(_p(dw), dw.numel(), _stream()), "zero")
-    return gemm_raw(O, K, M, dy2d, O, False, x2d, K, False, dw, K, splitk=sk)
+    return gemm_raw(O, K, M, dy2d, O, False, x2d, K, False, dw, K, splitk=sk, grad=True)
 
 
 def colsum(x2d, out=None):

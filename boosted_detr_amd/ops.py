@@ -371,16 +371,16 @@ def attention_core(Q: torch.Tensor, Kt: torch.Tensor, V: torch.Tensor, heads: in
         sP, sO = (heads * q * kk, q * kk), (heads * q * d, q * d)
         # dP[q][k] = sum_d dO[q][d] V[k][d]
         dP = K.empty(B, heads, q, kk, like=Q)
-        K.gemm_raw(q, kk, d, gO, d, True, V, D, True, dP, kk, nb0=B, nb1=heads, sa=sO, sb=(kk * D, d), sc=sP)
+        K.gemm_raw(q, kk, d, gO, d, True, V, D, True, dP, kk, nb0=B, nb1=heads, sa=sO, sb=(kk * D, d), sc=sP, grad=True)
         # dV[k][d] = sum_q P[q][k] dO[q][d]
         dV = K.empty(B, kk, D, like=Q)
-        K.gemm_raw(kk, d, q, P, kk, False, gO, d, False, dV, D, nb0=B, nb1=heads, sa=sP, sb=sO, sc=(kk * D, d))
+        K.gemm_raw(kk, d, q, P, kk, False, gO, d, False, dV, D, nb0=B, nb1=heads, sa=sP, sb=sO, sc=(kk * D, d), grad=True)
         dS = K.softmax_rows_bwd(P.view(-1, kk), dP.view(-1, kk), scale, out=dP.view(-1, kk)).view(B, heads, q, kk)
         # dQ[q][d] = sum_k dS[q][k] K[k][d] ;  dK[k][d] = sum_q dS[q][k] Q[q][d]
         dQ = K.empty(B, q, D, like=Q)
-        K.gemm_raw(q, d, kk, dS, kk, True, Kt, D, False, dQ, D, nb0=B, nb1=heads, sa=sP, sb=(kk * D, d), sc=(q * D, d))
+        K.gemm_raw(q, d, kk, dS, kk, True, Kt, D, False, dQ, D, nb0=B, nb1=heads, sa=sP, sb=(kk * D, d), sc=(q * D, d), grad=True)
         dK = K.empty(B, kk, D, like=Q)
-        K.gemm_raw(kk, d, q, dS, kk, False, Q, D, False, dK, D, nb0=B, nb1=heads, sa=sP, sb=(q * D, d), sc=(kk * D, d))
+        K.gemm_raw(kk, d, q, dS, kk, False, Q, D, False, dK, D, nb0=B, nb1=heads, sa=sP, sb=(q * D, d), sc=(kk * D, d), grad=True)
         return _own(dQ), _own(dK), _own(dV)
 
     _rec([O], [Q, Kt, V], backward)

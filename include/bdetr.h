@@ -25,12 +25,25 @@
 extern "C" {
 #endif
 
-#define BDETR_ABI_VERSION 1
+#define BDETR_ABI_VERSION 2
 
 int         bdetr_abi_version(void);
 const char* bdetr_last_error(void);
 /* number of CUs of the current device (used by the host to size split-K) */
 int         bdetr_device_cus(void);
+
+/* Arithmetic of the conv/GEMM family (inputs and outputs are always fp32):
+ *  BDETR_GEMM_FP32    every product on v_mfma_f32_32x32x2_f32 (exact fp32 products);
+ *  BDETR_GEMM_BF16X3  every operand is split on the fly into hi + lo bf16 halves and a product is
+ *                     hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation
+ *                     (~2^-18 relative error per product; TensorFlow's TF32 default is 2^-11);
+ *  BDETR_GEMM_MIXED   (default) forward products - conv2d_fwd and GEMMs with grad == 0 - are exact
+ *                     fp32 (class ids, match indices and ReLU masks are decided by them), gradient
+ *                     products - conv2d_bwd_* and GEMMs with grad != 0 - are split-bf16.
+ * The env variable BDETR_GEMM_PRECISION=fp32|bf16x3|mixed picks the initial value. */
+enum { BDETR_GEMM_FP32 = 0, BDETR_GEMM_BF16X3 = 1, BDETR_GEMM_MIXED = 2 };
+int         bdetr_set_gemm_precision(int mode);
+int         bdetr_get_gemm_precision(void);
 
 /* Live profiling of the MFMA (igemm) kernel family for bench.py's roofline leg: when enabled,
  * every conv/GEMM launch is bracketed by hipEvents on its own stream.  bdetr_prof_read (after a
@@ -106,6 +119,7 @@ typedef struct {
     const float* b; int64_t ldb, sb0, sb1; int b_rcontig;
     float*       c; int64_t ldc, sc0, sc1;
     const float* bias; float alpha; int act; int accumulate; int splitk;
+    int grad;                /* != 0: a gradient (backward) product - see BDETR_GEMM_MIXED */
 } bdetr_gemm_desc;
 int bdetr_gemm(const bdetr_gemm_desc* g, void* stream);
 /* n (1..4) independent GEMMs that share J, R, leading dimensions, operand flavours and epilogue flags
