@@ -1,0 +1,76 @@
+"""The three arithmetic policies of the conv/GEMM family (include/bdetr.h: BDETR_GEMM_FP32 / BF16X3 / MIXED)
+against fp64 products.  Tolerances: exact-fp32 MFMA 2e-5 x max|ref| (fp32 round-off over the sum), split-bf16
+6e-5 x max|ref| (2^-18 per product).  Every operand flavour (r-/x-contiguous, im2col patch gather, flipped
+taps), the 64x64 and 128x128 split tiles, split-K atomics and the grouped launch run in split mode here."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from test_kernels_gpu import close, dev, rnd
+
+pytestmark = pytest.mark.gpu
+TOL = {"fp32": 2e-5, "bf16x3": 6e-5}
+
+
+@pytest.fixture(params=["fp32", "bf16x3"])
+def mode(request, cuda):
+    from boosted_detr_amd import kernels as k
+    prev = k.set_gemm_precision(request.param)
+    assert k.get_gemm_precision() == request.param
+    yield request.param
+    k.set_gemm_precision(prev)
+
+
+def test_default_policy_is_mixed(cuda):
+    from boosted_detr_amd import kernels as k
+    assert k.get_gemm_precision() == "mixed"
+    # forward product exact, gradient product split: on a long reduction the split error is ~8x the fp32 one
+    x, w = rnd(512, 4096, seed=1), rnd(256, 4096, seed=2)
+    ref = x.double() @ w.double().T
+    e_fwd = (k.linear_fwd(dev(x), dev(w), None, 0).cpu().double() - ref).norm() / ref.norm()
+    dy = rnd(512, 256, seed=3)
+    ref_b = dy.double() @ w.double()
+    e_bwd = (k.linear_bwd_data(dev(dy), dev(w)).cpu().double() - ref_b).norm() / ref_b.norm()
+    assert e_fwd < 1.5e-6 and 1.5e-6 < e_bwd < 1e-5, (float(e_fwd), float(e_bwd))
+
+
+@pytest.mark.parametrize("M,K,O", [(300, 256, 256), (6400, 256, 1024), (1600, 1024, 256), (130, 52, 48), (4000, 64, 64), (25600, 128, 512)])
+def test_linear_all_flavours(mode, M, K, O):
+    from boosted_detr_amd import kernels as k
+    x, w, b, dy = rnd(M, K, seed=1), rnd(O, K, seed=2, scale=K ** -0.5), rnd(O, seed=3), rnd(M, O, seed=4)
+    close(k.linear_fwd(dev(x), dev(w), dev(b), 1), (x.double() @ w.double().T + b.double()).relu(), rtol=TOL[mode])
+    close(k.linear_bwd_data(dev(dy), dev(w)), dy.double() @ w.double(), rtol=TOL[mode])
+    close(k.linear_bwd_weight(dev(dy), dev(x)), dy.double().T @ x.double(), rtol=TOL[mode])
+
+
+@pytest.mark.parametrize("N,H,W,C,K,R,stride,pad", [(2, 20, 20, 64, 64, 3, 1, 1), (2, 20, 20, 256, 128, 1, 2, 0), (1, 9, 11, 128, 32, 3, 1, 1),
+                                                    (3, 7, 7, 512, 2048, 1, 1, 0), (4, 40, 40, 256, 256, 3, 1, 1), (2, 32, 32, 4, 64, 7, 2, 3)])
+def test_conv_all_flavours(mode, N, H, W, C, K, R, stride, pad):
+    from boosted_detr_amd import kernels as k
+    x, w, b = rnd(N, H, W, C, seed=1), rnd(K, R, R, C, seed=2, scale=(R * R * C) ** -0.5), rnd(K, seed=3)
+    g = k.ConvGeom(N, H, W, C, K, R, R, stride, pad)
+    y, (ps, pq, n) = k.conv2d_fwd(dev(x), dev(w), dev(b), g, 0, want_stats=True)
+    xt = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    wt = w.double().permute(0, 3, 1, 2).requires_grad_(True)
+    ref = F.conv2d(xt, wt, b.double(), stride=stride, padding=pad)
+    close(y, ref.permute(0, 2, 3, 1), rtol=TOL[mode])
+    close(ps.sum(0), ref.permute(0, 2, 3, 1).reshape(-1, K).sum(0), rtol=1e-4)
+    dy = rnd(*ref.shape, seed=4).double()
+    ref.backward(dy)
+    dyn = dy.permute(0, 2, 3, 1).float()
+    if R != 7:
+        close(k.conv2d_bwd_data(dev(dyn), dev(w), g), xt.grad.permute(0, 2, 3, 1), rtol=TOL[mode])
+    close(k.conv2d_bwd_weight(dev(x), dev(dyn), g), wt.grad.permute(0, 2, 3, 1), rtol=max(TOL[mode], 5e-5))
+
+
+def test_grouped_launch(mode):
+    from boosted_detr_amd import kernels as k
+    xs = [rnd(m, 256, seed=m) for m in (400, 400, 100)]
+    ws = [rnd(256, 256, seed=7 + i, scale=1 / 16) for i in range(3)]
+    bs = [rnd(256, seed=11 + i) for i in range(3)]
+    ys = k.linear_fwd_group([dev(x) for x in xs], [dev(w) for w in ws], [dev(b) for b in bs])
+    for y, x, w, b in zip(ys, xs, ws, bs):
+        close(y, x.double() @ w.double().T + b.double(), rtol=TOL[mode])
+    dxs = k.linear_bwd_data_group([dev(x) for x in xs], [dev(w) for w in ws])
+    for dx, x, w in zip(dxs, xs, ws):
+        close(dx, x.double() @ w.double(), rtol=TOL[mode])
