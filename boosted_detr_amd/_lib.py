@@ -6,9 +6,10 @@ resolved, importing this module's ``lib()`` raises.  Nothing here imports ``orac
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
-_LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libbdetr.so"
+_LIB_PATH = Path(os.environ.get("BDETR_LIB") or Path(__file__).resolve().parent / "csrc" / "libbdetr.so")   # BDETR_LIB: kernel experiments
 _lib = None
 
 c_f32p = C.c_void_p     # device pointers are passed as integers (tensor.data_ptr())

@@ -16,6 +16,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -33,18 +34,37 @@ constexpr int NTHREADS = 256;
 // k per lane): [x][16 dwords hi | 16 dwords lo | 4 pad], one dword = the k-pair (2t, 2t+1); the
 // 16-byte chunks of a row are XOR-swizzled with (x >> 4) & 7 so that both the ds_read_b128 fragment
 // reads and the transposing ds_write_b32 of x-contiguous operands are bank-conflict free.
+//
+// Split-fp16 ("fp16x3", forward products): the same layout and MFMA count with fp16 halves, which carry
+// 11 + 11 significant bits - fp32-grade products (~2^-23) - but only fp16's exponent range.  The lo half
+// is therefore stored scaled by 2^11 (it is ~2^-12 of the value and would otherwise sink into fp16
+// subnormals for |x| < 0.25) and the two cross products accumulate in a second accumulator that is folded
+// in with 2^-11 in the epilogue.  Operand magnitudes must stay below 65504 (beyond that the hi half is
+// inf and the output NaN - loud, not silent); gradients, whose range is unbounded, never take this path.
 constexpr int SLD = 36;      // dwords per LDS row in split mode
+enum { AR_FP32 = 0, AR_BF16X3 = 1, AR_FP16X3 = 2 };
+constexpr float LO_SCALE = 2048.f;
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+template <int ARITH>
 __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigned& lo) {
     f32x2 v; v[0] = x0; v[1] = x1;
-    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));        // v_cvt_pk_bf16_f32 (RNE)
-    f32x2 r;
-    r[0] = x0 - __builtin_bit_cast(float, hi << 16);                              // exact in fp32
-    r[1] = x1 - __builtin_bit_cast(float, hi & 0xFFFF0000u);
-    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+    if (ARITH == AR_BF16X3) {
+        hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));        // v_cvt_pk_bf16_f32 (RNE)
+        f32x2 r;
+        r[0] = x0 - __builtin_bit_cast(float, hi << 16);                              // exact in fp32
+        r[1] = x1 - __builtin_bit_cast(float, hi & 0xFFFF0000u);
+        lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+    } else {
+        const f16x2 h = __builtin_convertvector(v, f16x2);                            // v_cvt_pk_f16_f32 (RNE)
+        hi = __builtin_bit_cast(unsigned, h);
+        const f32x2 r = (v - __builtin_convertvector(h, f32x2)) * LO_SCALE;           // residual exact, then 2^11
+        lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+    }
 }
 
 // ----------------------------------------------------------------------------------------
@@ -179,7 +199,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return v;
 }
 
-template <int BM, int BN, int WM, int WN, class LA, bool A_RC, class LB, bool B_RC, bool SPLIT>
+template <int BM, int BN, int WM, int WN, class LA, bool A_RC, class LB, bool B_RC, int ARITH>
 __global__ __launch_bounds__(NTHREADS, 2)
 void igemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
 {
@@ -191,6 +211,7 @@ void igemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
     using GB = TileGeom<BN, B_RC>;
     static_assert(GA::NV >= 1 && GB::NV >= 1, "tile too small for 256 threads");
 
+    constexpr bool SPLIT = ARITH != AR_FP32;
     constexpr int A_FLOATS = SPLIT ? BM * SLD : GA::LDS_FLOATS;
     constexpr int B_FLOATS = SPLIT ? BN * SLD : GB::LDS_FLOATS;
     constexpr int STAGE_FLOATS = A_FLOATS + B_FLOATS;
@@ -291,13 +312,14 @@ void igemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
             else      rb[p] = LB::load(rsB, opb, LB::row_ctx(opb, r0 + rowB[p], b_rows), j0 + colB[p], b_cols);
         }
     };
-    auto write_split = [&](unsigned* base, bool rc, int nv, const f32x4* r, const int* ldsoff) {
+    auto write_split = [&](unsigned* base, bool rc, auto nv_c, const f32x4* r, const int* ldsoff) {
+        constexpr int nv = decltype(nv_c)::value;
         if (rc) {
 #pragma unroll
             for (int p = 0; p < nv; ++p) {
                 unsigned h0, l0, h1, l1;
-                split2(r[p][0], r[p][1], h0, l0);
-                split2(r[p][2], r[p][3], h1, l1);
+                split2<ARITH>(r[p][0], r[p][1], h0, l0);
+                split2<ARITH>(r[p][2], r[p][3], h1, l1);
                 u32x2 hi, lo;
                 hi[0] = h0; hi[1] = h1; lo[0] = l0; lo[1] = l1;
                 unsigned* row = base + (ldsoff[p] >> 5);
@@ -313,7 +335,7 @@ void igemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     unsigned hi, lo;
-                    split2(r[p][e], r[p + 1][e], hi, lo);
+                    split2<ARITH>(r[p][e], r[p + 1][e], hi, lo);
                     row[e * SLD + w] = hi;
                     row[e * SLD + (w ^ 16)] = lo;
                 }
@@ -323,8 +345,8 @@ void igemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
     auto write_stage = [&](int buf, const f32x4 (&ra)[GA::NV], const f32x4 (&rb)[GB::NV]) {
         if (SPLIT) {
             unsigned* st = reinterpret_cast<unsigned*>(lds + buf * STAGE_FLOATS);
-            write_split(st, A_RC, GA::NV, ra, ldsoffA);
-            write_split(st + A_FLOATS, B_RC, GB::NV, rb, ldsoffB);
+            write_split(st, A_RC, std::integral_constant<int, GA::NV>{}, ra, ldsoffA);
+            write_split(st + A_FLOATS, B_RC, std::integral_constant<int, GB::NV>{}, rb, ldsoffB);
             return;
         }
 #pragma unroll
@@ -333,13 +355,20 @@ void igemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
         for (int p = 0; p < GB::NV; ++p) *reinterpret_cast<f32x4*>(lds + buf * STAGE_FLOATS + GA::LDS_FLOATS + ldsoffB[p]) = rb[p];
     };
 
-    f32x16 acc[TM][TN];
+    constexpr int TM2 = ARITH == AR_FP16X3 ? TM : 1, TN2 = ARITH == AR_FP16X3 ? TN : 1;
+    f32x16 acc[TM][TN], acc2[TM2][TN2];       // acc2: the 2^11-scaled cross products of the fp16 split
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int b = 0; b < TN; ++b)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+#pragma unroll
+    for (int a = 0; a < TM2; ++a)
+#pragma unroll
+        for (int b = 0; b < TN2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc2[a][b][e] = 0.f;
 
     auto compute = [&](int buf) {
         if (SPLIT) {
@@ -347,28 +376,38 @@ void igemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
             const unsigned* qB = qA + A_FLOATS;
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) {
-                bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+                u32x4 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
                 for (int a = 0; a < TM; ++a) {
                     const int xb = wm * WTM + a * 32 + li;
                     const int w = ((ks * 2 + lh) ^ ((xb >> 4) & 7)) << 2;
-                    ah[a] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qA + xb * SLD + w));
-                    al[a] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qA + xb * SLD + (w ^ 16)));
+                    ah[a] = *reinterpret_cast<const u32x4*>(qA + xb * SLD + w);
+                    al[a] = *reinterpret_cast<const u32x4*>(qA + xb * SLD + (w ^ 16));
                 }
 #pragma unroll
                 for (int b = 0; b < TN; ++b) {
                     const int xb = wn * WTN + b * 32 + li;
                     const int w = ((ks * 2 + lh) ^ ((xb >> 4) & 7)) << 2;
-                    bh[b] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qB + xb * SLD + w));
-                    bl[b] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qB + xb * SLD + (w ^ 16)));
+                    bh[b] = *reinterpret_cast<const u32x4*>(qB + xb * SLD + w);
+                    bl[b] = *reinterpret_cast<const u32x4*>(qB + xb * SLD + (w ^ 16));
                 }
 #pragma unroll
                 for (int a = 0; a < TM; ++a)
 #pragma unroll
                     for (int b = 0; b < TN; ++b) {
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+                        if constexpr (ARITH == AR_BF16X3) {
+#define BF8(v) __builtin_bit_cast(bf16x8, v)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF8(al[a]), BF8(bh[b]), acc[a][b], 0, 0, 0);
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF8(ah[a]), BF8(bl[b]), acc[a][b], 0, 0, 0);
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF8(ah[a]), BF8(bh[b]), acc[a][b], 0, 0, 0);
+#undef BF8
+                        } else if constexpr (ARITH == AR_FP16X3) {
+#define H8(v) __builtin_bit_cast(f16x8, v)
+                            acc2[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(al[a]), H8(bh[b]), acc2[a][b], 0, 0, 0);
+                            acc2[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(ah[a]), H8(bl[b]), acc2[a][b], 0, 0, 0);
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(ah[a]), H8(bh[b]), acc[a][b], 0, 0, 0);
+#undef H8
+                        }
                     }
             }
             return;
@@ -450,6 +489,14 @@ void igemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
         int oh = rem / g.rm_OW; int ow = rem - oh * g.rm_OW;
         return ((int64_t)n * g.rm_H + (int64_t)oh * g.rm_stride) * g.rm_W + (int64_t)ow * g.rm_stride;
     };
+    if constexpr (ARITH == AR_FP16X3) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[a][b][e] += acc2[a][b][e] * (1.f / LO_SCALE);
+    }
     // bias + activation in registers, BN partial statistics from registers
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
@@ -551,11 +598,18 @@ int gemm_mode() {
     if (g_gemm_mode < 0) {
         const char* e = getenv("BDETR_GEMM_PRECISION");
         g_gemm_mode = !e ? BDETR_GEMM_MIXED : (!strcmp(e, "fp32") || !strcmp(e, "f32")) ? BDETR_GEMM_FP32
-                    : !strcmp(e, "bf16x3") ? BDETR_GEMM_BF16X3 : BDETR_GEMM_MIXED;
+                    : !strcmp(e, "bf16x3") ? BDETR_GEMM_BF16X3 : !strcmp(e, "split") ? BDETR_GEMM_SPLIT : BDETR_GEMM_MIXED;
     }
     return g_gemm_mode;
 }
-bool use_split(bool grad) { const int m = gemm_mode(); return m == BDETR_GEMM_BF16X3 || (m == BDETR_GEMM_MIXED && grad); }
+int use_split(bool grad) {      // -> AR_* of one product
+    switch (gemm_mode()) {
+        case BDETR_GEMM_FP32:   return AR_FP32;
+        case BDETR_GEMM_BF16X3: return AR_BF16X3;
+        case BDETR_GEMM_SPLIT:  return grad ? AR_BF16X3 : AR_FP16X3;
+        default:                return grad ? AR_BF16X3 : AR_FP32;
+    }
+}
 
 TileChoice choose_tile(int I, int J, int zdim, bool both_rc, bool split) {
     static int forced_bm = -1, forced_bn = -1;
@@ -610,7 +664,7 @@ void prof_begin(hipStream_t st, double flops, int I, int J, int R, int z, int bm
 }
 void prof_end(hipStream_t st) { hipEventRecord(g_prof_recs.back().e1, st); }
 
-template <int BM, int BN, int WM, int WN, class LA, bool A_RC, class LB, bool B_RC, bool SPLIT = false>
+template <int BM, int BN, int WM, int WN, class LA, bool A_RC, class LB, bool B_RC, int ARITH = AR_FP32>
 int launch_cfg(const typename LA::Op& a, const typename LB::Op& b, GemmParams g, int zdim, hipStream_t st) {
     g.tiles_i = (int)cdiv64(g.I, BM);
     g.tiles_j = (int)cdiv64(g.J, BN);
@@ -618,21 +672,29 @@ int launch_cfg(const typename LA::Op& a, const typename LB::Op& b, GemmParams g,
     g.vec_store = (g.J % 4 == 0) && (g.ldc % 4 == 0) && (g.sc0 % 4 == 0) && (g.sc1 % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.c) & 15) == 0);
     const bool prof = g_prof_on;
     if (prof) prof_begin(st, 2.0 * (double)g.I * (double)g.J * (double)g.R * (g.splitk > 1 ? 1.0 : (double)zdim), g.I, g.J, g.R, zdim, BM, BN,
-                         (SPLIT ? 10000 : 0) + LoaderId<LA>::v * 1000 + (A_RC ? 100 : 0) + LoaderId<LB>::v * 10 + (B_RC ? 1 : 0));
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, LA, A_RC, LB, B_RC, SPLIT>), grid, dim3(NTHREADS), 0, st, a, b, g);
+                         ARITH * 10000 + LoaderId<LA>::v * 1000 + (A_RC ? 100 : 0) + LoaderId<LB>::v * 10 + (B_RC ? 1 : 0));
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, LA, A_RC, LB, B_RC, ARITH>), grid, dim3(NTHREADS), 0, st, a, b, g);
     if (prof) prof_end(st);
     return bdetr_launch_status("igemm");
 }
 
 template <class LA, bool A_RC, class LB, bool B_RC>
-int launch_any(const typename LA::Op& a, const typename LB::Op& b, GemmParams g, int zdim, hipStream_t st, bool split, bool small_only = false) {
-    TileChoice t = small_only ? TileChoice{64, 64} : choose_tile(g.I, g.J, zdim, A_RC && B_RC, split);
+int launch_any(const typename LA::Op& a, const typename LB::Op& b, GemmParams g, int zdim, hipStream_t st, int arith, bool small_only = false) {
+    if (arith == AR_FP16X3 && !(A_RC && B_RC)) arith = AR_FP32;     // the fp16 split is built for the forward flavour only
+    TileChoice t = small_only ? TileChoice{64, 64} : choose_tile(g.I, g.J, zdim, A_RC && B_RC, arith != AR_FP32);
     if constexpr (LoaderId<LA>::v != 3 && LoaderId<LB>::v != 3) {
         // 16-byte loaders only; the narrow 128x32 tile (J <= 32: tiny heads) stays on the fp32 kernel
-        if (split && t.bn >= 64) {
-            if (t.bm == 128 && t.bn == 128) return launch_cfg<128, 128, 2, 2, LA, A_RC, LB, B_RC, true>(a, b, g, zdim, st);
-            if (t.bm == 128 && t.bn == 64)  return launch_cfg<128, 64, 2, 2, LA, A_RC, LB, B_RC, true>(a, b, g, zdim, st);
-            return launch_cfg<64, 64, 2, 2, LA, A_RC, LB, B_RC, true>(a, b, g, zdim, st);
+        if (arith == AR_BF16X3 && t.bn >= 64) {
+            if (t.bm == 128 && t.bn == 128) return launch_cfg<128, 128, 2, 2, LA, A_RC, LB, B_RC, AR_BF16X3>(a, b, g, zdim, st);
+            if (t.bm == 128 && t.bn == 64)  return launch_cfg<128, 64, 2, 2, LA, A_RC, LB, B_RC, AR_BF16X3>(a, b, g, zdim, st);
+            return launch_cfg<64, 64, 2, 2, LA, A_RC, LB, B_RC, AR_BF16X3>(a, b, g, zdim, st);
+        }
+        if constexpr (A_RC && B_RC) {
+            if (arith == AR_FP16X3 && t.bn >= 64) {
+                if (t.bm == 128 && t.bn == 128) return launch_cfg<128, 128, 2, 2, LA, A_RC, LB, B_RC, AR_FP16X3>(a, b, g, zdim, st);
+                if (t.bm == 128 && t.bn == 64)  return launch_cfg<128, 64, 2, 2, LA, A_RC, LB, B_RC, AR_FP16X3>(a, b, g, zdim, st);
+                return launch_cfg<64, 64, 2, 2, LA, A_RC, LB, B_RC, AR_FP16X3>(a, b, g, zdim, st);
+            }
         }
     }
     if (t.bm == 128 && t.bn == 128) return launch_cfg<128, 128, 2, 2, LA, A_RC, LB, B_RC>(a, b, g, zdim, st);
@@ -645,7 +707,7 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 
 // number of partial-statistics rows the epilogue writes for an (I,J) problem: tiles_i * WM
 int stat_chunks(int I, int J) {
-    TileChoice t = choose_tile(I, J, 1, true, use_split(false));
+    TileChoice t = choose_tile(I, J, 1, true, use_split(false) != AR_FP32);
     const int wm = (t.bm == 128 && t.bn == 32) ? 4 : 2;
     return (int)cdiv64(I, t.bm) * wm;
 }
@@ -663,7 +725,7 @@ void init_params(GemmParams& g) {
 extern "C" int bdetr_device_cus(void) { return num_cus(); }
 
 extern "C" int bdetr_set_gemm_precision(int mode) {
-    BDETR_CHECK_ARG(mode == BDETR_GEMM_FP32 || mode == BDETR_GEMM_BF16X3 || mode == BDETR_GEMM_MIXED, "bdetr_set_gemm_precision: unknown mode %d", mode);
+    BDETR_CHECK_ARG(mode >= BDETR_GEMM_FP32 && mode <= BDETR_GEMM_SPLIT, "bdetr_set_gemm_precision: unknown mode %d", mode);
     g_gemm_mode = mode;
     return 0;
 }
@@ -735,7 +797,7 @@ extern "C" int bdetr_gemm_grouped(const bdetr_gemm_desc* d, int n, void* stream)
     DenseOp b{f.b, f.ldb, 0, 0, f.b_rcontig ? f.J : f.R, f.b_rcontig ? f.R : f.J};
     hipStream_t st = (hipStream_t)stream;
     const bool arc = f.a_rcontig != 0, brc = f.b_rcontig != 0;
-    const bool sp = use_split(f.grad != 0);
+    const int sp = use_split(f.grad != 0);
     if (arc && brc)   return launch_any<DenseLoader<4>, true, DenseLoader<4>, true>(a, b, g, n, st, sp);
     if (arc && !brc)  return launch_any<DenseLoader<4>, true, DenseLoader<4>, false>(a, b, g, n, st, sp);
     if (!arc && !brc) return launch_any<DenseLoader<4>, false, DenseLoader<4>, false>(a, b, g, n, st, sp);
@@ -769,7 +831,7 @@ extern "C" int bdetr_gemm(const bdetr_gemm_desc* d, void* stream) {
     };
     const bool v4 = vec_ok(a) && vec_ok(b);
     const bool arc = d->a_rcontig != 0, brc = d->b_rcontig != 0;
-    const bool sp = use_split(d->grad != 0);
+    const int sp = use_split(d->grad != 0);
     if (v4) {
         if (arc && brc)   return launch_any<DenseLoader<4>, true, DenseLoader<4>, true>(a, b, g, zdim, st, sp);
         if (arc && !brc)  return launch_any<DenseLoader<4>, true, DenseLoader<4>, false>(a, b, g, zdim, st, sp);
@@ -777,10 +839,10 @@ extern "C" int bdetr_gemm(const bdetr_gemm_desc* d, void* stream) {
         return launch_any<DenseLoader<4>, false, DenseLoader<4>, true>(a, b, g, zdim, st, sp, true);
     }
     // unaligned fallback (scalar HBM loads): only tiny problems take it (82-wide heads, T=49 attention)
-    if (arc && brc)   return launch_any<DenseLoader<1>, true, DenseLoader<1>, true>(a, b, g, zdim, st, false, true);
-    if (arc && !brc)  return launch_any<DenseLoader<1>, true, DenseLoader<1>, false>(a, b, g, zdim, st, false, true);
-    if (!arc && !brc) return launch_any<DenseLoader<1>, false, DenseLoader<1>, false>(a, b, g, zdim, st, false, true);
-    return launch_any<DenseLoader<1>, false, DenseLoader<1>, true>(a, b, g, zdim, st, false, true);
+    if (arc && brc)   return launch_any<DenseLoader<1>, true, DenseLoader<1>, true>(a, b, g, zdim, st, AR_FP32, true);
+    if (arc && !brc)  return launch_any<DenseLoader<1>, true, DenseLoader<1>, false>(a, b, g, zdim, st, AR_FP32, true);
+    if (!arc && !brc) return launch_any<DenseLoader<1>, false, DenseLoader<1>, false>(a, b, g, zdim, st, AR_FP32, true);
+    return launch_any<DenseLoader<1>, false, DenseLoader<1>, true>(a, b, g, zdim, st, AR_FP32, true);
 }
 
 static int check_conv(const bdetr_conv_desc* d, const char* who) {
@@ -857,7 +919,7 @@ extern "C" int bdetr_conv2d_bwd_data(const float* dy, const float* w, float* dx,
 extern "C" int bdetr_conv2d_bwd_weight_splitk(const bdetr_conv_desc* d) {
     if (check_conv(d, "bdetr_conv2d_bwd_weight_splitk")) return -1;
     const int M = d->N * d->OH * d->OW, Kd = d->R * d->S * d->C;
-    TileChoice t = choose_tile(d->K, Kd, 1, false, use_split(true));
+    TileChoice t = choose_tile(d->K, Kd, 1, false, use_split(true) != AR_FP32);
     int64_t tiles = cdiv64(d->K, t.bm) * cdiv64(Kd, t.bn);
     int64_t want = 3LL * num_cus();
     int64_t sk = cdiv64(want, tiles);

@@ -30,8 +30,8 @@ def set_launch_stream(handle: Optional[int]) -> Optional[int]:
     return prev
 
 
-GEMM_FP32, GEMM_BF16X3, GEMM_MIXED = 0, 1, 2
-_GEMM_MODES = {"fp32": GEMM_FP32, "bf16x3": GEMM_BF16X3, "mixed": GEMM_MIXED}
+GEMM_FP32, GEMM_BF16X3, GEMM_MIXED, GEMM_SPLIT = 0, 1, 2, 3
+_GEMM_MODES = {"fp32": GEMM_FP32, "bf16x3": GEMM_BF16X3, "mixed": GEMM_MIXED, "split": GEMM_SPLIT}
 
 
 def set_gemm_precision(mode) -> int:
@@ -46,6 +46,22 @@ def set_gemm_precision(mode) -> int:
 def get_gemm_precision() -> str:
     code = _lib.lib().bdetr_get_gemm_precision()
     return next(k for k, v in _GEMM_MODES.items() if v == code)
+
+
+class gemm_precision:
+    """``with gemm_precision('split'): ...`` - scoped arithmetic policy (None leaves it alone)."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = set_gemm_precision(self.mode) if self.mode is not None else None
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            set_gemm_precision(self.prev)
+        return False
 
 
 def _stream() -> int:

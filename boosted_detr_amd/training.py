@@ -213,6 +213,12 @@ class Model(Layer):
         self._step_metrics: Dict[str, torch.Tensor] = {}
         self._dp: Optional[DataParallel] = None
         self.steps_done = 0
+        # Arithmetic of the conv/GEMM family during a training step (include/bdetr.h): 'split' = split-fp16
+        # forward + split-bf16 gradient products.  The fp16 halves need |operand| < 65504, which the batch-
+        # normalised / layer-normalised training forward guarantees; inference and anything outside
+        # forward_backward run under the library default ('mixed': exact fp32 forward).  The environment
+        # variable BDETR_GEMM_PRECISION, when set, wins (None = leave the library's mode alone).
+        self.train_gemm_precision = None if os.environ.get("BDETR_GEMM_PRECISION") else "split"
         self.validate_matching = False      # fit() turns this on: it synchronises every step anyway (host logging)
 
     # -- Keras bookkeeping -----------------------------------------------------------------
@@ -253,9 +259,10 @@ class Model(Layer):
         tape = Tape()
         prev = K.set_launch_stream(torch.cuda.current_stream().cuda_stream)     # pin the launch stream for the step
         try:
-            with recording(tape):
-                y_pred = self(data, training=True)
-            tape.backward({id(t): t for t in self._loss_roots})     # parameter gradients land in Variable.grad (ops.GradSink)
+            with K.gemm_precision(self.train_gemm_precision):
+                with recording(tape):
+                    y_pred = self(data, training=True)
+                tape.backward({id(t): t for t in self._loss_roots})     # parameter gradients land in Variable.grad (ops.GradSink)
         finally:
             K.set_launch_stream(prev)
         join_side_stream()                                      # weight-gradient GEMMs ran on the side stream

@@ -37,11 +37,16 @@ int         bdetr_device_cus(void);
  *  BDETR_GEMM_BF16X3  every operand is split on the fly into hi + lo bf16 halves and a product is
  *                     hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation
  *                     (~2^-18 relative error per product; TensorFlow's TF32 default is 2^-11);
- *  BDETR_GEMM_MIXED   (default) forward products - conv2d_fwd and GEMMs with grad == 0 - are exact
- *                     fp32 (class ids, match indices and ReLU masks are decided by them), gradient
- *                     products - conv2d_bwd_* and GEMMs with grad != 0 - are split-bf16.
- * The env variable BDETR_GEMM_PRECISION=fp32|bf16x3|mixed picks the initial value. */
-enum { BDETR_GEMM_FP32 = 0, BDETR_GEMM_BF16X3 = 1, BDETR_GEMM_MIXED = 2 };
+ *  BDETR_GEMM_MIXED   forward products - conv2d_fwd and GEMMs with grad == 0 - are exact fp32 (class
+ *                     ids, match indices and ReLU masks are decided by them), gradient products -
+ *                     conv2d_bwd_* and GEMMs with grad != 0 - are split-bf16;
+ *  BDETR_GEMM_SPLIT   gradient products split-bf16; forward products split-fp16: hi + lo fp16 halves
+ *                     (11 + 11 significant bits, the lo half kept scaled by 2^11 in a second
+ *                     accumulator), three products on v_mfma_f32_32x32x16_f16 - fp32-grade products
+ *                     (~2^-23), but forward operands must stay below 65504 in magnitude (a larger
+ *                     value yields NaN).
+ * The env variable BDETR_GEMM_PRECISION=fp32|bf16x3|mixed|split picks the initial value. */
+enum { BDETR_GEMM_FP32 = 0, BDETR_GEMM_BF16X3 = 1, BDETR_GEMM_MIXED = 2, BDETR_GEMM_SPLIT = 3 };
 int         bdetr_set_gemm_precision(int mode);
 int         bdetr_get_gemm_precision(void);
 

@@ -74,3 +74,45 @@ def test_grouped_launch(mode):
     dxs = k.linear_bwd_data_group([dev(x) for x in xs], [dev(w) for w in ws])
     for dx, x, w in zip(dxs, xs, ws):
         close(dx, x.double() @ w.double(), rtol=TOL[mode])
+
+
+def test_training_step_runs_split_and_restores_policy(cuda):
+    """Model.forward_backward scopes the 'split' policy (fp16x3 forward, bf16x3 gradients) and restores the
+    library default afterwards; the forward it produces stays within 1e-3 of the fp64 oracle and is at least
+    as close to it as the exact-fp32 policy is on this case."""
+    import numpy as np
+    from boosted_detr_amd import kernels as k
+    from oracle import detr_oracle as O
+    from test_model_gpu import build_model
+    cfg = O.CONFIG1
+    batch = O.make_batch(cfg, 2, 20, seed=1234, num_objects=[3, 7])
+    params = O.make_params(cfg, seed=0)
+    out, _ = O.train_step_grads(cfg, params, batch, dtype=torch.float64)
+    want = out.cat_preds.detach().numpy()
+    errs = {}
+    for mode in ("split", "fp32"):
+        model = build_model(cfg, False)
+        assert model.train_gemm_precision == "split"
+        model.train_gemm_precision = mode
+        model.forward_backward(batch)
+        model.set_weights_dict(params)
+        y = model.forward_backward(batch)
+        assert k.get_gemm_precision() == "mixed"
+        errs[mode] = np.abs(y[0].cpu().numpy().astype(np.float64) - want).max() / np.abs(want).max()
+    assert errs["split"] < 1e-3 and errs["split"] < 2 * errs["fp32"] + 1e-6, errs
+
+
+def test_fp16_split_range(cuda):
+    """Split-fp16 forward products: fp32-grade inside [1.2e-4, 65504), graceful below (absolute error < 2^-35),
+    NaN - not a silently wrong number - above."""
+    from boosted_detr_amd import kernels as k
+    x, w = rnd(256, 512, seed=1).clamp(-3, 3), rnd(128, 512, seed=2) / 16
+    ref = x.double() @ w.double().T
+    with k.gemm_precision("split"):
+        e = lambda y, r: float((y.cpu().double() - r).norm() / r.norm())
+        assert e(k.linear_fwd(dev(x), dev(w), None, 0), ref) < 4e-7
+        assert e(k.linear_fwd(dev(x * 2e4), dev(w), None, 0), ref * 2e4) < 4e-7
+        assert e(k.linear_fwd(dev(x * 1e-6), dev(w), None, 0), ref * 1e-6) < 1e-4
+        big = x.clone(); big[3, 7] = 7e4
+        y = k.linear_fwd(dev(big), dev(w), None, 0)
+        assert not torch.isfinite(y[3]).any() and torch.isfinite(y[4]).all()
