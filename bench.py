@@ -29,6 +29,11 @@ if ROOT not in sys.path:
 
 METRIC = "images/sec training step (fwd+matcher+loss+bwd), 640x640 N=100"
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)
+PEAK_16BIT_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16/f16 MFMA peak (v_mfma_f32_32x32x16_{bf16,f16})
+# A split product costs three 16-bit MFMA products, so the algorithmic-FLOP peak of the split arithmetics
+# is a third of the 16-bit MFMA peak.
+ARITH = {0: ("fp32 MFMA", PEAK_FP32_MFMA_TFLOPS), 1: ("split-bf16 (3 bf16 MFMA products)", PEAK_16BIT_MFMA_TFLOPS / 3),
+         2: ("split-fp16 (3 f16 MFMA products)", PEAK_16BIT_MFMA_TFLOPS / 3)}
 GFLOP_PER_IMAGE = 201.7                # 3 x fwd - conv1 bwd-data at 640^2, 6+6, N=100
 
 
@@ -102,6 +107,17 @@ def hbm_traffic_per_launch():
             return round(json.load(f)["hbm_bytes_per_launch"])
     except Exception:
         return None
+
+
+def arithmetic_note(model) -> str:
+    from boosted_detr_amd import kernels as K
+    mode = model.train_gemm_precision or K.get_gemm_precision()
+    return {"split": "fp32 tensors; conv/GEMM products: forward split-fp16 (hi+lo f16 halves, 3 MFMA products, fp32 accumulate; "
+                     "measured error below the exact-fp32 MFMA path), gradients split-bf16 (3 MFMA products, ~2^-18); attention, "
+                     "normalisation, losses fp32; matcher fp64",
+            "mixed": "fp32 tensors; forward conv/GEMM products exact fp32 MFMA, gradient products split-bf16; matcher fp64",
+            "fp32": "fp32 everywhere (exact fp32 MFMA); matcher fp64",
+            "bf16x3": "fp32 tensors; every conv/GEMM product split-bf16; matcher fp64"}[mode]
 
 
 def usable_cores() -> int:
@@ -243,12 +259,27 @@ def main():
         _lib.check(L.bdetr_prof_read(ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)), "prof_read")
         if os.environ.get("BDETR_PROF_DUMP"):
             L.bdetr_prof_dump(os.environ["BDETR_PROF_DUMP"].encode())
+        by_arith, peak_ms = {}, 0.0
+        for code, (label, peak) in ARITH.items():
+            m_, n_, f_ = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+            _lib.check(L.bdetr_prof_read_arith(code, ctypes.byref(m_), ctypes.byref(n_), ctypes.byref(f_)), "prof_read_arith")
+            if n_.value:
+                a_ = f_.value / (m_.value * 1e-3) / 1e12
+                by_arith[label] = {"achieved": round(a_, 2), "peak": round(peak, 1), "frac": round(a_ / peak, 4),
+                                   "launches_per_step": n_.value // args.steps, "kernel_ms_per_step": round(m_.value / args.steps, 3),
+                                   "gflop_per_step": round(f_.value / args.steps / 1e9, 1)}
+                peak_ms += f_.value / (peak * 1e12) * 1e3
         L.bdetr_prof_enable(0)
         if ms.value > 0 and n.value > 0:
             ach = fl.value / (ms.value * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": hbm_traffic_per_launch(),
-                    "kernel": "igemm_kernel (fp32 MFMA implicit-GEMM family: conv fwd/bwd-data/bwd-weight, dense, attention GEMMs)",
+            # the family mixes arithmetics: its peak is the FLOP-weighted harmonic mean of their peaks, i.e.
+            # (algorithmic FLOPs) / (time the same launches would take at each one's MFMA peak)
+            peak = fl.value / (peak_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "traffic": hbm_traffic_per_launch(),
+                    "kernel": "igemm_kernel (MFMA implicit-GEMM family: conv fwd/bwd-data/bwd-weight, dense; algorithmic FLOPs = 2*I*J*R)",
+                    "peak_note": "FLOP-weighted harmonic mean of the per-arithmetic peaks in by_arithmetic (fp32 MFMA 157.3; split = 2500/3)",
+                    "by_arithmetic": by_arith,
                     "launches_per_step": n.value // args.steps, "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
                     "avg_launch_gflop": round(fl.value / n.value / 1e9, 3),
                     "kernel_ms_per_step": round(ms.value / args.steps, 3), "gflop_per_step": round(fl.value / args.steps / 1e9, 1),
@@ -271,7 +302,7 @@ def main():
         out = {
             "metric": METRIC, "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "arithmetic": arithmetic_note(model), "data": "synthetic",
             "config": {"workload": workload_name(args), "per_gpu_batch": args.batch, "global_batch": global_batch,
                        "parallelism": f"dp{world}", "gflop_per_image_algorithmic": GFLOP_PER_IMAGE if is_config2(args) else None},
             "tflops_algorithmic": round(value * GFLOP_PER_IMAGE / 1e3, 2) if is_config2(args) else None,

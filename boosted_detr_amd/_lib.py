@@ -54,6 +54,7 @@ SIGNATURES = {
     "bdetr_get_gemm_precision": (I, []),
     "bdetr_prof_enable": (I, [I]),
     "bdetr_prof_read": (I, [P, P, P]),
+    "bdetr_prof_read_arith": (I, [I, P, P, P]),
     "bdetr_prof_dump": (I, [C.c_char_p]),
     "bdetr_image_prep": (I, [P, I, I, I, P, I, I, P]),
     "bdetr_augment_ws_floats": (I, [I]),

@@ -752,18 +752,24 @@ extern "C" int bdetr_prof_dump(const char* path) {
     return 0;
 }
 
-extern "C" int bdetr_prof_read(double* total_ms, int64_t* launches, double* flops) {
-    double ms = 0, fl = 0;
+static int prof_sum(int arith, double* total_ms, int64_t* launches, double* flops) {
+    double ms = 0, fl = 0; int64_t n = 0;
     for (auto& r : g_prof_recs) {
+        if (arith >= 0 && r.kind / 10000 != arith) continue;
         float t = 0.f;
         hipError_t e = hipEventElapsedTime(&t, r.e0, r.e1);
         if (e != hipSuccess) { bdetr_set_error("bdetr_prof_read: %s", hipGetErrorString(e)); return (int)e; }
-        ms += t; fl += r.flops;
+        ms += t; fl += r.flops; ++n;
     }
     if (total_ms) *total_ms = ms;
-    if (launches) *launches = (int64_t)g_prof_recs.size();
+    if (launches) *launches = n;
     if (flops) *flops = fl;
     return 0;
+}
+extern "C" int bdetr_prof_read(double* total_ms, int64_t* launches, double* flops) { return prof_sum(-1, total_ms, launches, flops); }
+extern "C" int bdetr_prof_read_arith(int arith, double* total_ms, int64_t* launches, double* flops) {
+    BDETR_CHECK_ARG(arith >= AR_FP32 && arith <= AR_FP16X3, "bdetr_prof_read_arith: arith must be 0 (fp32), 1 (bf16x3) or 2 (fp16x3)");
+    return prof_sum(arith, total_ms, launches, flops);
 }
 
 // Up to 4 independent dense GEMMs with the same J, R, operand flavours and epilogue in ONE launch

@@ -56,6 +56,8 @@ int         bdetr_get_gemm_precision(void);
  * (2*I*J*R per GEMM) of everything launched since bdetr_prof_enable(1). */
 int bdetr_prof_enable(int on);
 int bdetr_prof_read(double* total_ms, int64_t* launches, double* flops);
+/* the same sums restricted to the launches that ran one arithmetic: 0 exact fp32, 1 split-bf16, 2 split-fp16 */
+int bdetr_prof_read_arith(int arith, double* total_ms, int64_t* launches, double* flops);
 /* debug aid: one CSV row per recorded launch (shape, tile, loader kinds, ms, GFLOP) */
 int bdetr_prof_dump(const char* path);
 
