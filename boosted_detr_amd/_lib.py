@@ -124,6 +124,10 @@ def lib():
         raise BdetrError(
             f"{_LIB_PATH} not found: the HIP extension is not built. Run `python -m boosted_detr_amd.build` "
             "(or __graft_entry__.build()). There is no CPU fallback in the product path.")
+    # One HIP runtime per process: PyTorch ships its own libamdhip64 and must load it first, so that this
+    # library's dependency resolves to the SAME copy (the host hands over torch's device pointers and
+    # stream handles).  Loaded the other way round, the second runtime finds "no ROCm-capable device".
+    import torch  # noqa: F401
     h = C.CDLL(str(_LIB_PATH))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(h, name)          # AttributeError if the library lacks a declared symbol
