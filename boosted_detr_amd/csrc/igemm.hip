@@ -611,7 +611,7 @@ int use_split(bool grad) {      // -> AR_* of one product
     }
 }
 
-TileChoice choose_tile(int I, int J, int zdim, bool both_rc, bool split) {
+TileChoice choose_tile(int I, int J, int zdim, bool both_rc, bool split, bool patch = false) {
     static int forced_bm = -1, forced_bn = -1;
     if (forced_bm < 0) {
         forced_bm = forced_bn = 0;
@@ -632,6 +632,10 @@ TileChoice choose_tile(int I, int J, int zdim, bool both_rc, bool split) {
         // (conv/dense forward) once it still yields ~a workgroup per CU; the transposing flavours and the
         // small problems stay on 64x64.
         if (both_rc && J % 128 == 0 && tiles(128, 128) * 4 >= 3LL * num_cus()) return {128, 128};
+        // 3x3 convolution gradients (im2col operand, R >= 1152): 128x128 is 15-25 % faster on stages 3-5
+        // (bench.py per-launch dump); the weight gradient gets its parallelism from split-K, so its rule must
+        // not depend on zdim (bdetr_conv2d_bwd_weight_splitk sizes z from this same choice)
+        if (patch && !both_rc && I % 128 == 0 && J % 128 == 0 && (zdim > 1 || tiles(128, 128) * 4 >= 3LL * num_cus())) return {128, 128};
         return {64, 64};
     }
     if (tiles(128, 128) >= 16LL * num_cus() && J >= 1024) return {128, 128};
@@ -681,7 +685,8 @@ int launch_cfg(const typename LA::Op& a, const typename LB::Op& b, GemmParams g,
 template <class LA, bool A_RC, class LB, bool B_RC>
 int launch_any(const typename LA::Op& a, const typename LB::Op& b, GemmParams g, int zdim, hipStream_t st, int arith, bool small_only = false) {
     if (arith == AR_FP16X3 && !(A_RC && B_RC)) arith = AR_FP32;     // the fp16 split is built for the forward flavour only
-    TileChoice t = small_only ? TileChoice{64, 64} : choose_tile(g.I, g.J, zdim, A_RC && B_RC, arith != AR_FP32);
+    constexpr bool PATCH = LoaderId<LA>::v == 1 || LoaderId<LB>::v == 1;
+    TileChoice t = small_only ? TileChoice{64, 64} : choose_tile(g.I, g.J, g.splitk > 1 ? 2 : zdim, A_RC && B_RC, arith != AR_FP32, PATCH);
     if constexpr (LoaderId<LA>::v != 3 && LoaderId<LB>::v != 3) {
         // 16-byte loaders only; the narrow 128x32 tile (J <= 32: tiny heads) stays on the fp32 kernel
         if (arith == AR_BF16X3 && t.bn >= 64) {
@@ -925,7 +930,7 @@ extern "C" int bdetr_conv2d_bwd_data(const float* dy, const float* w, float* dx,
 extern "C" int bdetr_conv2d_bwd_weight_splitk(const bdetr_conv_desc* d) {
     if (check_conv(d, "bdetr_conv2d_bwd_weight_splitk")) return -1;
     const int M = d->N * d->OH * d->OW, Kd = d->R * d->S * d->C;
-    TileChoice t = choose_tile(d->K, Kd, 1, false, use_split(true) != AR_FP32);
+    TileChoice t = choose_tile(d->K, Kd, 2, false, use_split(true) != AR_FP32, !(d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0));
     int64_t tiles = cdiv64(d->K, t.bm) * cdiv64(Kd, t.bn);
     int64_t want = 3LL * num_cus();
     int64_t sk = cdiv64(want, tiles);
