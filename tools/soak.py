@@ -1,4 +1,5 @@
-"""Soak: N training steps at config 2, reporting step time and allocator high-water marks (leak check)."""
+"""Soak: N training steps at config 2, reporting step time, loss and allocator high-water marks (leak check).
+usage: python tools/soak.py [steps] [policy]   - run once per arithmetic policy to compare the loss trajectories."""
 import sys, time, torch
 sys.path.insert(0, '.')
 import bench
@@ -10,6 +11,9 @@ host = bench.make_batch(16, 640, 640, 100, 82, 1234)
 batch = {"image": to_device(host["image"]), "category": host["category"], "attribute": host["attribute"], "bbox": to_device(host["bbox"]), "num_objects": to_device(host["num_objects"], torch.int32)}
 c, h = m.Tokenization([host["category"], host["attribute"]]); m.Tokenization.call = lambda i, training=False: (c, h)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+if len(sys.argv) > 2:
+    m.train_gemm_precision = sys.argv[2]          # split | mixed | fp32 | bf16x3
+print('policy', m.train_gemm_precision, flush=True)
 for blk in range(N // 50):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(50):
