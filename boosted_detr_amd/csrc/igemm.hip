@@ -1,8 +1,9 @@
-// igemm.hip - fp32 MFMA implicit-GEMM family for gfx950 (MI355X).
+// igemm.hip - MFMA implicit-GEMM family for gfx950 (MI355X): fp32 tensors, three arithmetics.
 //
 // One kernel template computes   C[i][j] (+)= act(alpha * sum_r A(i,r) * B(j,r) + bias[j])
-// with v_mfma_f32_32x32x2_f32 (exact fp32, 64-lane wavefronts), where each operand is
-// produced by a *loader* over its natural row-major matrix:
+// on 64-lane wavefronts with v_mfma_f32_32x32x2_f32 (exact fp32) or, splitting every operand into two
+// 16-bit halves in registers, with three v_mfma_f32_32x32x16_{bf16,f16} per product (see "Split" below).
+// Each operand is produced by a *loader* over its natural row-major matrix:
 //   DenseLoader  - plain matrix with a leading dimension (Dense layers, 1x1 convs, attention)
 //   PatchLoader  - on-the-fly im2col rows of an NHWC tensor (conv fwd / bwd-data / bwd-weight)
 //   WFlipLoader  - OHWI conv weights read as [(tap',k)][c] with flipped taps (3x3 bwd-data)
