@@ -92,3 +92,42 @@ def test_config2_batch16_properties(cuda):
     for _ in range(3):
         l1 = model.logs_to_host(model.train_step(host))["loss"]
     assert l1 < l0, (l0, l1)                                           # the optimizer step descends
+
+
+def test_config3_boosted_fashionpedia_batch2_matches_oracle(cuda):
+    """BASELINE.json configs[2]: the config-2 shapes + the attribute head (Fashionpedia sizes: 46 categories,
+    294 attributes, attribute_weight 1) and the BoostedDETR stack of 3 weak learners, against the CPU oracle."""
+    from boosted_detr_amd import parameters, transformers
+    from boosted_detr_amd.boosted_model import BoostedDETR
+    from oracle import detr_oracle as O
+    cfg = O.Config(image_size=(640, 640), num_object_preds=100, num_encoder_blocks=6, num_decoder_blocks=3, boosted=True)
+    batch = O.make_batch(cfg, 2, 40, seed=99, num_objects=[11, 37])
+    params = O.make_params(cfg, seed=1)
+    transformers.AttentionBlock.dropout_rate = 0.0
+    transformers.FeedForwardBlock.dropout_rate = 0.0
+    model = BoostedDETR(num_object_preds=100, image_size=(640, 640), num_encoder_blocks=6, num_encoder_heads=8, encoder_dim=256,
+                        num_decoder_blocks=3, num_decoder_heads=8, decoder_dim=256, num_panoptic_heads=1, panoptic_dim=32,
+                        vocab_dict=parameters.synthetic_vocab(46, 294), attribute_weight=1.0)
+    model.forward_backward(batch)
+    model.set_weights_dict(params)
+    y = model.forward_backward(batch)
+    torch.cuda.synchronize()
+    out, grads = O.train_step_grads(cfg, params, batch, dtype=torch.float32)
+    cat, att, box = [t.cpu().numpy() for t in y]
+    assert rel_err(cat, out.cat_preds.detach().numpy()) < 1e-3
+    assert rel_err(att, out.attribute_preds.detach().numpy()) < 1e-3
+    assert rel_err(box, out.box_preds.detach().numpy()) < 1e-3
+    assert np.array_equal(cat.argmax(-1), out.cat_preds.detach().numpy().argmax(-1))       # class ids bit-exact
+    match = model.loss_fn.last_match.cpu().numpy()                                          # last learner's assignment
+    want = -np.ones_like(match)
+    for b, (r, c) in enumerate(out.learner_losses[-1].matches):
+        want[b, r] = c
+    assert np.array_equal(match, want)
+    logs = model.logs_to_host(model.step_logs())
+    ref = float(out.loss_vector.detach().double().mean())
+    assert abs(logs["loss"] - ref) <= 1e-3 * abs(ref)
+    for name in ("EncoderBackbone/resnet50/conv4_block3_2_conv/kernel", "AttributePredictionHead_1/Dense/kernel"):
+        v = [x for x in model.variables if x.name == name][0]
+        g, w = v.grad_numpy().astype(np.float64).ravel(), grads[name].astype(np.float64).ravel()
+        cos = g @ w / (np.linalg.norm(g) * np.linalg.norm(w))
+        assert cos > 0.995, (name, cos)
