@@ -109,6 +109,14 @@ def hbm_traffic_per_launch():
         return None
 
 
+def dtype_note(model) -> str:
+    from boosted_detr_amd import kernels as K
+    mode = model.train_gemm_precision or K.get_gemm_precision()
+    return {"split": "f32 (conv/GEMM products as 3 split-f16 [fwd] / split-bf16 [grad] MFMA products, f32 accumulate)",
+            "mixed": "f32 (gradient conv/GEMM products as 3 split-bf16 MFMA products, f32 accumulate)",
+            "fp32": "f32", "bf16x3": "f32 (conv/GEMM products as 3 split-bf16 MFMA products, f32 accumulate)"}[mode]
+
+
 def arithmetic_note(model) -> str:
     from boosted_detr_amd import kernels as K
     mode = model.train_gemm_precision or K.get_gemm_precision()
@@ -302,7 +310,7 @@ def main():
         out = {
             "metric": METRIC, "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "arithmetic": arithmetic_note(model), "data": "synthetic",
+            "dtype": dtype_note(model), "arithmetic": arithmetic_note(model), "data": "synthetic",
             "config": {"workload": workload_name(args), "per_gpu_batch": args.batch, "global_batch": global_batch,
                        "parallelism": f"dp{world}", "gflop_per_image_algorithmic": GFLOP_PER_IMAGE if is_config2(args) else None},
             "tflops_algorithmic": round(value * GFLOP_PER_IMAGE / 1e3, 2) if is_config2(args) else None,
