@@ -48,6 +48,15 @@ def get_gemm_precision() -> str:
     return next(k for k, v in _GEMM_MODES.items() if v == code)
 
 
+def demote_split_forward() -> None:
+    """Frozen BatchNormalization (moving statistics) does not guarantee normalised activations, so the rest of this
+    forward must not take the range-limited split-fp16 path: 'split' -> 'mixed' (exact-fp32 forward, same gradient
+    arithmetic).  The enclosing ``gemm_precision`` scope restores the policy afterwards."""
+    L = _lib.lib()
+    if L.bdetr_get_gemm_precision() == GEMM_SPLIT:
+        check(L.bdetr_set_gemm_precision(GEMM_MIXED), "set_gemm_precision")
+
+
 class gemm_precision:
     """``with gemm_precision('split'): ...`` - scoped arithmetic policy (None leaves it alone)."""
 

@@ -98,6 +98,7 @@ def _bn_forward(y2d, rows, Cc, parts, bn: BNState, use_batch_stats: bool, bessel
             parts = K.colstats(y2d)
         mean, rstd = K.bn_stats(rows, Cc, parts, bn.eps, bn.momentum, bessel, bn.moving_mean.value, bn.moving_var.value, like=y2d)
     else:
+        K.demote_split_forward()
         mean, rstd = K.bn_stats_frozen(bn.moving_mean.value, bn.moving_var.value, bn.eps)
     out = K.bn_apply(y2d, mean, rstd, bn.gamma.value, bn.beta.value, residual2d, relu)
     return out, mean, rstd

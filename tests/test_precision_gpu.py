@@ -116,3 +116,28 @@ def test_fp16_split_range(cuda):
         big = x.clone(); big[3, 7] = 7e4
         y = k.linear_fwd(dev(big), dev(w), None, 0)
         assert not torch.isfinite(y[3]).any() and torch.isfinite(y[4]).all()
+
+
+def test_frozen_batchnorm_demotes_the_fp16_forward(cuda):
+    """Frozen BatchNormalization (moving statistics) need not normalise: with fresh moving statistics the config-1
+    backbone activations exceed the f16 range.  The step must notice (ops._bn_forward -> kernels.demote_split_forward),
+    finish its forward on the exact-fp32 path and still match the fp64 oracle; the policy is restored afterwards."""
+    import numpy as np
+    from boosted_detr_amd import kernels as k
+    from oracle import detr_oracle as O
+    from test_model_gpu import build_model
+    cfg = O.CONFIG1
+    batch = O.make_batch(cfg, 2, 20, seed=1234, num_objects=[3, 7])
+    params = O.make_params(cfg, seed=0)
+    model = build_model(cfg, False)
+    model.forward_backward(batch)
+    model.set_weights_dict(params)
+    for layer in (model.EncoderBackbone, model.BackboneNeck, model.CategoryPredictionHead, model.AttributePredictionHead, model.BoxPredictionHead):
+        layer.trainable = False                     # every BatchNormalization of the model on moving statistics, like the oracle's frozen_bn
+    assert model.train_gemm_precision == "split"
+    y = model.forward_backward(batch)
+    assert k.get_gemm_precision() == "mixed"
+    out, _ = O.train_step_grads(cfg, params, batch, dtype=torch.float64, frozen_bn=True)
+    for got, want in zip(y, (out.cat_preds, out.attribute_preds, out.box_preds)):
+        g, w = got.cpu().numpy().astype(np.float64), want.detach().numpy()
+        assert np.isfinite(g).all() and np.abs(g - w).max() <= 1e-3 * np.abs(w).max()
