@@ -50,6 +50,8 @@ SIGNATURES = {
     "bdetr_abi_version": (I, []),
     "bdetr_last_error": (C.c_char_p, []),
     "bdetr_device_cus": (I, []),
+    "bdetr_low_priority_stream_create": (I, [P]),
+    "bdetr_stream_priority_range": (I, [P, P]),
     "bdetr_set_gemm_precision": (I, [I]),
     "bdetr_get_gemm_precision": (I, []),
     "bdetr_prof_enable": (I, [I]),

@@ -229,7 +229,16 @@ def side_stream() -> Optional["torch.cuda.Stream"]:
     if not _SIDE["enabled"]:
         return None
     if _SIDE["stream"] is None:
-        _SIDE["stream"] = torch.cuda.Stream(device=device())
+        # lowest priority class: the dispatcher serves the critical path first, the leaves fill the rest
+        # (torch.cuda.Stream only offers normal / high, so the stream comes from the C ABI)
+        if _os.environ.get("BDETR_SIDE_PRIORITY", "low") == "low":
+            import ctypes as _C
+            from . import _lib
+            h = _C.c_void_p()
+            _lib.check(_lib.lib().bdetr_low_priority_stream_create(_C.byref(h)), "low_priority_stream_create")
+            _SIDE["stream"] = torch.cuda.ExternalStream(h.value, device=device())
+        else:
+            _SIDE["stream"] = torch.cuda.Stream(device=device())
     return _SIDE["stream"]
 
 

@@ -32,6 +32,12 @@ const char* bdetr_last_error(void);
 /* number of CUs of the current device (used by the host to size split-K) */
 int         bdetr_device_cus(void);
 
+/* A non-blocking stream of the lowest priority class of the device (never destroyed: process lifetime), for
+ * work that must not delay the caller's critical path (the host's weight-gradient side stream), and the
+ * device's priority range (numerically larger = lower priority). */
+int         bdetr_low_priority_stream_create(void** stream_out);
+int         bdetr_stream_priority_range(int* least, int* greatest);
+
 /* Arithmetic of the conv/GEMM family (inputs and outputs are always fp32):
  *  BDETR_GEMM_FP32    every product on v_mfma_f32_32x32x2_f32 (exact fp32 products);
  *  BDETR_GEMM_BF16X3  every operand is split on the fly into hi + lo bf16 halves and a product is
