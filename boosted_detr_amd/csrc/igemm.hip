@@ -711,6 +711,13 @@ int launch_any(const typename LA::Op& a, const typename LB::Op& b, GemmParams g,
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// The loaders address an operand with 32-bit byte offsets from its base (raw buffer loads, NUM_RECORDS):
+// one operand matrix / tensor must span less than 4 GB.  Larger batches shard over GPUs (or are split by the
+// caller); outputs are addressed with 64-bit pointers and have no such limit.
+constexpr int64_t MAX_OPERAND_ELEMS = (int64_t)(NUM_RECORDS / 4) - 64;
+bool span_ok(int64_t elems) { return elems >= 0 && elems <= MAX_OPERAND_ELEMS; }
+int64_t dense_span(const DenseOp& o) { return (int64_t)(o.rows - 1) * o.ld + o.cols; }
+
 // number of partial-statistics rows the epilogue writes for an (I,J) problem: tiles_i * WM
 int stat_chunks(int I, int J) {
     TileChoice t = choose_tile(I, J, 1, true, use_split(false) != AR_FP32);
@@ -794,6 +801,8 @@ extern "C" int bdetr_gemm_grouped(const bdetr_gemm_desc* d, int n, void* stream)
                         "bdetr_gemm_grouped: problems must share J, R, leading dimensions, flavours and epilogue");
         BDETR_CHECK_ARG(e.grad == d[0].grad, "bdetr_gemm_grouped: problems must share the grad flag");
         BDETR_CHECK_ARG((e.nb0 <= 1) && (e.nb1 <= 1) && e.splitk <= 1, "bdetr_gemm_grouped: no batching / split-K inside a group");
+        BDETR_CHECK_ARG(span_ok((int64_t)(e.a_rcontig ? e.I : e.R) * e.lda) && span_ok((int64_t)(e.b_rcontig ? e.J : e.R) * e.ldb),
+                        "bdetr_gemm_grouped: operand %d spans 4 GB or more (32-bit buffer offsets)", k);
         g.ga[k] = e.a; g.gb[k] = e.b; g.gc[k] = e.c; g.gbias[k] = e.bias; g.gI[k] = e.I;
         if (e.I > maxI) maxI = e.I;
         v4 = v4 && aligned16(e.a) && aligned16(e.b) && aligned16(e.c);
@@ -826,6 +835,8 @@ extern "C" int bdetr_gemm(const bdetr_gemm_desc* d, void* stream) {
 
     DenseOp a{d->a, d->lda, d->sa0, d->sa1, d->a_rcontig ? d->I : d->R, d->a_rcontig ? d->R : d->I};
     DenseOp b{d->b, d->ldb, d->sb0, d->sb1, d->b_rcontig ? d->J : d->R, d->b_rcontig ? d->R : d->J};
+    BDETR_CHECK_ARG(span_ok(dense_span(a)) && span_ok(dense_span(b)),
+                    "bdetr_gemm: an operand matrix spans 4 GB or more (32-bit buffer offsets); split the problem");
     GemmParams g; init_params(g);
     g.I = d->I; g.J = d->J; g.R = d->R; g.nb1 = nb1;
     g.c = d->c; g.ldc = d->ldc; g.sc0 = d->sc0; g.sc1 = d->sc1;
@@ -865,6 +876,8 @@ static int check_conv(const bdetr_conv_desc* d, const char* who) {
     BDETR_CHECK_ARG(d->OH == (d->H + 2 * d->pad - d->R) / d->stride + 1 && d->OW == (d->W + 2 * d->pad - d->S) / d->stride + 1,
                     "%s: OH/OW inconsistent with geometry", who);
     BDETR_CHECK_ARG((int64_t)d->N * d->OH * d->OW < (1LL << 31) && (int64_t)d->R * d->S * d->C < (1LL << 31), "%s: problem too large", who);
+    BDETR_CHECK_ARG(span_ok((int64_t)d->N * d->H * d->W * d->C) && span_ok((int64_t)d->N * d->OH * d->OW * d->K) && span_ok((int64_t)d->K * d->R * d->S * d->C),
+                    "%s: a tensor spans 4 GB or more (the loaders use 32-bit buffer offsets); use a smaller per-GPU batch", who);
     return 0;
 }
 

@@ -116,3 +116,19 @@ def test_config2_parameter_count(cuda):
     assert model.count_params() == 31_006_681
     assert sum(v.num_params for v in model.trainable_variables) == 30_944_345
     assert model.num_categories == 82 and model.num_attributes == 3
+
+
+def test_operands_of_4GB_or_more_are_refused(cuda):
+    """The loaders use 32-bit buffer offsets: a tensor that spans >= 4 GB must be rejected with an error, not
+    read through wrapped offsets (the check runs before any memory is touched, so tiny dummy buffers suffice)."""
+    import ctypes as C
+    from boosted_detr_amd import _lib, kernels as k
+    L = _lib.lib()
+    t = torch.zeros(64, device="cuda")
+    g = k.ConvGeom(700, 640, 640, 4, 64, 1, 1, 1, 0)             # 700*640*640*4 floats = 4.59 GB input
+    d = g.desc()
+    rc = L.bdetr_conv2d_fwd(t.data_ptr(), t.data_ptr(), None, t.data_ptr(), C.byref(d), 0, None, None, None)
+    assert rc != 0 and b"4 GB" in L.bdetr_last_error()
+    gd = _lib.GemmDesc(1 << 20, 64, 1024, 1, 1, t.data_ptr(), 1024, 0, 0, 1, t.data_ptr(), 1024, 0, 0, 1, t.data_ptr(), 64, 0, 0, None, 1.0, 0, 0, 1, 0)
+    rc = L.bdetr_gemm(C.byref(gd), None)                          # A: 2^20 x 1024 floats = 4 GiB
+    assert rc != 0 and b"4 GB" in L.bdetr_last_error()
