@@ -276,8 +276,11 @@ void igemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
             const int rt = v / vpr, c4 = v - rt * vpr;
             row = rt; col = 4 * c4; ldsoff = rt * lds_ld + 4 * c4;
         } else if (rc) {
+            // 8 lanes cover one row's 16 hi dwords; a 32-lane ds_write_b64 pass therefore touches 4 rows, which
+            // are chosen 4 apart (36 * 4 = 16 mod 64 banks): rows q = 16G + 4a + b -> 16G + 4b + a.
             const int v = tid + NTHREADS * p;
-            const int rt = v / vpr, c4 = v - rt * vpr;           // vpr = 8: k = 4*c4 .. 4*c4+3
+            const int q = v / vpr, c4 = v - q * vpr;             // vpr = 8: k = 4*c4 .. 4*c4+3
+            const int rt = (q & ~15) | ((q & 3) << 2) | ((q >> 2) & 3);
             row = rt; col = 4 * c4;
             ldsoff = rt * SLD * 32 + ((((c4 >> 1) ^ ((rt >> 4) & 7)) << 2) | ((c4 & 1) << 1));
         } else {
