@@ -173,6 +173,40 @@ def test_batchnorm_train(cuda, rows, C, relu, res):
         assert torch.equal(dx2, dx) and torch.equal(dg2, dg) and torch.equal(db2, db)
 
 
+@pytest.mark.parametrize("rows,C", [(409600, 64), (25600, 1024), (6400, 2048), (102400, 128), (1000, 4)])
+def test_batchnorm_reductions_large_and_repeatable(cuda, rows, C):
+    """The BN statistics (conv-epilogue partials -> fold -> finalize) and the BN backward reduction at the model's
+    large shapes: right against fp64, and bit-identical over repeated launches (fixed summation order)."""
+    from boosted_detr_amd import kernels as k
+    x = rnd(rows, C, seed=1) * 1.5 + 0.3
+    dout = rnd(rows, C, seed=7)
+    gamma, beta = 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)
+    xd_, dd_, gd_, bd_ = dev(x), dev(dout), dev(gamma), dev(beta)
+    eps = 1.001e-5
+    xd = x.double()
+    m, v = xd.mean(0), xd.var(0, unbiased=False)
+    # forward statistics through the many-partials path (one partial row per 32 rows, like the conv epilogue writes them)
+    nparts = (rows + 31) // 32
+    pad = nparts * 32 - rows
+    xp = torch.cat([x, torch.zeros(pad, C)]) if pad else x
+    psum = dev(xp.view(nparts, 32, C).sum(1)); psq = dev((xp * xp).view(nparts, 32, C).sum(1))
+    first = None
+    for it in range(12):
+        mmd, mvd = dev(torch.zeros(C)), dev(torch.ones(C))
+        mean, rstd = k.bn_stats(rows, C, (psum, psq, nparts), eps, 0.99, True, mmd, mvd, like=mmd)
+        dx, dg, db, _ = k.bn_bwd(dd_, None, xd_, mean, rstd, gd_, True, False, beta=bd_)
+        got = [t.clone() for t in (mean, rstd, mmd, mvd, dg, db)]
+        if first is None:
+            first = got
+            close(mean, m, rtol=1e-5); close(rstd, 1 / torch.sqrt(v + eps), rtol=1e-4)
+            xh = (xd - m) / torch.sqrt(v + eps)
+            mask = (xh * gamma.double() + beta.double()) > 0
+            g = dout.double() * mask
+            close(db, g.sum(0), rtol=1e-4); close(dg, (g * xh).sum(0), rtol=1e-4)
+        else:
+            assert all(torch.equal(a, b) for a, b in zip(first, got)), it
+
+
 def test_batchnorm_frozen(cuda):
     from boosted_detr_amd import kernels as k
     rows, C = 500, 128
