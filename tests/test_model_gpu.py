@@ -36,7 +36,6 @@ def run_pair(cfg, batch, boosted=False):
     from oracle import detr_oracle as O
     params = O.make_params(cfg, seed=0)
     model = build_model(cfg, boosted)
-    model(batch, training=False) if False else None
     # build-by-first-call, then load the oracle's weights (Keras layouts)
     model.forward_backward(batch)
     model.set_weights_dict(params)
