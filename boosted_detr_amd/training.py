@@ -170,6 +170,9 @@ class TerminateOnNaN(Callback):
         loss = (logs or {}).get("loss")
         if loss is not None and not math.isfinite(loss):
             print(f"Batch {batch}: Invalid loss, terminating training")
+            if getattr(self.model, "train_gemm_precision", None) == "split":
+                print("  (policy 'split' multiplies forward operands as fp16 halves: a forward activation beyond 65504 turns into NaN; "
+                      "model.train_gemm_precision = 'mixed' keeps the forward on the exact-fp32 MFMA)")
             self.model.stop_training = True
 
 
