@@ -211,11 +211,12 @@ def main():
     model = build_model(args)
     host = make_batch(args.batch, args.image, args.image_w or args.image, 100, 48 if args.fashionpedia else 82, seed=1234 + rank,
                       A=296 if args.fashionpedia else 3)
-    # inputs resident in HBM before the timed region (targets are pre-tokenised int ids)
-    batch = {"image": to_device(host["image"]), "category": host["category"], "attribute": host["attribute"],
+    # inputs resident in HBM before the timed region; the targets are integer ids (the reference's StringLookup is a
+    # host-side dictionary lookup outside the path), so Tokenization runs its device branch every step: range check +
+    # multi-hot scatter (bdetr_tokens_prepare) - the timed region is the unmodified train_step
+    batch = {"image": to_device(host["image"]), "category": to_device(host["category"], torch.int32),
+             "attribute": to_device(host["attribute"], torch.int32),
              "bbox": to_device(host["bbox"]), "num_objects": to_device(host["num_objects"], torch.int32)}
-    cat_ids, att_hot = model.Tokenization([host["category"], host["attribute"]])
-    model.Tokenization.call = lambda inputs, training=False: (cat_ids, att_hot)      # tokenised once, resident
 
     if world > 1:
         model.distribute()

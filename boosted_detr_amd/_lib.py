@@ -59,6 +59,7 @@ SIGNATURES = {
     "bdetr_prof_read_arith": (I, [I, P, P, P]),
     "bdetr_prof_dump": (I, [C.c_char_p]),
     "bdetr_image_prep": (I, [P, I, I, I, P, I, I, P]),
+    "bdetr_tokens_prepare": (I, [P, P, L, I, I, I, P, P, P]),
     "bdetr_augment_ws_floats": (I, [I]),
     "bdetr_augment": (I, [P, P, P, P, I, I, I, P, P]),
     "bdetr_conv2d_fwd": (I, [P, P, P, P, C.POINTER(ConvDesc), I, P, P, P]),

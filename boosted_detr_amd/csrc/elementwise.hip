@@ -170,7 +170,32 @@ int ew_launch(const char* who, const float* a, const float* b, float* o, int64_t
     return bdetr_launch_status(who);
 }
 
+// Targets that are already integer ids and resident in HBM (tokenizers.py:40-82 after the StringLookup):
+// category ids are range-checked, attribute id slots are scattered into the multi-hot matrix
+// (one_hot + reduce_max over slots; PAD slots set bit 0).  An id outside its vocabulary maps to <OOV> = 1,
+// which is what StringLookup does with an unknown string.
+__global__ __launch_bounds__(256) void tokens_prepare_kernel(const int* __restrict__ cat_in, const int* __restrict__ att_in, int64_t rows, int slots,
+                                                             int C, int A, int* __restrict__ cat_out, float* __restrict__ hot) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
+        const int c = cat_in[r];
+        cat_out[r] = (unsigned)c < (unsigned)C ? c : 1;
+        float* h = hot + r * A;
+        for (int a = 0; a < A; ++a) h[a] = 0.f;
+        for (int s = 0; s < slots; ++s) {
+            const int a = att_in[r * slots + s];
+            h[(unsigned)a < (unsigned)A ? a : 1] = 1.f;
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int bdetr_tokens_prepare(const int* cat_ids, const int* att_ids, int64_t rows, int slots, int C, int A,
+                                    int* cat_out, float* att_hot, void* stream) {
+    BDETR_CHECK_ARG(cat_ids && att_ids && cat_out && att_hot && rows > 0 && slots >= 0 && C > 1 && A > 1, "bdetr_tokens_prepare: bad arguments");
+    hipLaunchKernelGGL(tokens_prepare_kernel, dim3(ew_grid(rows, 256, 1)), dim3(256), 0, (hipStream_t)stream, cat_ids, att_ids, rows, slots, C, A, cat_out, att_hot);
+    return bdetr_launch_status("tokens_prepare");
+}
 
 extern "C" int bdetr_image_prep(const float* in, int B, int h, int w, float* out, int H, int W, void* stream) {
     BDETR_CHECK_ARG(in && out && B > 0 && h > 0 && w > 0 && H > 0 && W > 0, "bdetr_image_prep: bad arguments");

@@ -55,6 +55,7 @@ class Variable:
         self.value: Optional[torch.Tensor] = None
         self.grad: Optional[torch.Tensor] = None
         self.grad_buf: Optional[torch.Tensor] = None   # persistent slice of the optimizer's flat gradient buffer
+        self._grad_flat: Optional[torch.Tensor] = None  # ... and the flat buffer it is a slice of (ops.GradSink checks it is live)
         self._grad_fresh = False                        # grad_buf already holds this step's gradient
 
     # layout conversion -----------------------------------------------------------------
@@ -101,20 +102,6 @@ class Variable:
 
     def reset_grad(self) -> None:
         self.grad, self._grad_fresh = None, False
-
-    def accumulate_grad(self, fn) -> None:
-        """``fn(out)`` writes this variable's gradient into ``out`` (or allocates when out is None)
-        and returns it.  The first contribution of a step lands directly in the optimizer's flat
-        buffer slice (no staging copy); later ones (shared layers) are added in place."""
-        if not self.needs_grad:
-            return
-        if self.grad is None and self.grad_buf is not None:
-            fn(self.grad_buf)
-            self.grad, self._grad_fresh = self.grad_buf, True
-        elif self.grad is None:
-            self.grad = fn(None)
-        else:
-            K.axpy_(1.0, fn(None).view(self.grad.shape), self.grad)
 
 
 # Keras initialisers (SURVEY S17) -- host-side numpy, seeded per variable name

@@ -113,6 +113,20 @@ def image_prep(image: torch.Tensor, H: int, W: int) -> torch.Tensor:
     return out
 
 
+def tokens_prepare(cat_ids: torch.Tensor, att_ids: torch.Tensor, C_: int, A: int):
+    """tokenizers.py:40-82 for targets that are already int32 ids in HBM: (range-checked category ids [B,M],
+    multi-hot attributes f32 [B,M,A])."""
+    _chk(cat_ids, att_ids, dtype=torch.int32)
+    if cat_ids.dim() == 3:
+        cat_ids = cat_ids[..., 0].contiguous()
+    B, M = cat_ids.shape
+    slots = att_ids.shape[2] if att_ids.dim() == 3 else 1
+    cat = torch.empty_like(cat_ids)
+    hot = torch.empty((B, M, A), dtype=torch.float32, device=cat_ids.device)
+    check(_lib.lib().bdetr_tokens_prepare(_p(cat_ids), _p(att_ids), B * M, slots, C_, A, _p(cat), _p(hot), _stream()), "tokens_prepare")
+    return cat, hot
+
+
 def augment(image: torch.Tensor, iparams: torch.Tensor, fparams: torch.Tensor) -> torch.Tensor:
     """pipeline.py:274-341 on the GPU.  image [B,H,W,3]; iparams int32 [B,4]; fparams f32 [B,3]."""
     _chk(image, fparams)

@@ -47,7 +47,7 @@ class MatchingAssignment(Layer):
         m = match.cpu().numpy()
         n = num_objects.cpu().numpy()
         for b in range(m.shape[0]):
-            want = min(int(n[b]), num_preds)
+            want = min(int(n[b]), num_preds, m.shape[1])      # the kernel clamps num_objects to the M padded rows
             if (m[b] >= 0).sum() != want:
                 raise ValueError("cost matrix is infeasible or contains invalid numeric entries")
 

@@ -47,20 +47,32 @@ def _own(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+_live_flat_grad = [None]
+
+
+def set_live_flat_grad(flat: Optional[torch.Tensor]) -> None:
+    """The flat gradient buffer that was zero-filled for THIS step (Model.forward_backward), or None.  A
+    Variable.grad_buf is only written in place when it is a slice of exactly this buffer: after compile(new
+    optimizer) or a freeze/unfreeze cycle a variable may still carry a slice of a retired buffer that holds an
+    earlier step's gradients, and the split-K atomics would add onto them."""
+    _live_flat_grad[0] = flat
+
+
 class GradSink:
     """Where a backward kernel writes one parameter's gradient.
 
-    direct: first contribution of the step and the optimizer has a flat buffer -> write in place.
-    temp  : later contribution (shared layer) or no optimizer yet -> temporary, added on commit.
+    direct: first contribution of the step and the variable owns a slice of the flat buffer zeroed this step -> in place.
+    temp  : later contribution (shared layer), no optimizer yet, or a stale slice -> temporary, added on commit.
     drop  : the variable is frozen but the kernel always produces the value -> scratch."""
 
     __slots__ = ("var", "buf", "mode")
 
     def __init__(self, var: Variable):
         self.var = var
+        live = _live_flat_grad[0]
         if not var.needs_grad:
             self.mode, self.buf = "drop", torch.empty_like(var.value)
-        elif var.grad is None and var.grad_buf is not None:
+        elif var.grad is None and var.grad_buf is not None and live is not None and getattr(var, "_grad_flat", None) is live:
             self.mode, self.buf = "direct", var.grad_buf      # zero-filled at the start of the step (Model.forward_backward)
         else:
             self.mode, self.buf = "temp", torch.empty_like(var.value)

@@ -48,6 +48,10 @@ class Tokenization(Layer):
     def lookup(self, arr, index) -> np.ndarray:
         a = np.asarray(arr)
         if a.dtype.kind in "iu":                       # already tokenised
+            if a.size and (a.min() < 0 or a.max() >= len(index)):
+                # the device kernels index prediction rows with these ids: an id outside the vocabulary is a caller
+                # error (tf.one_hot would silently give an all-zero row; StringLookup never produces one)
+                raise ValueError(f"token id outside the vocabulary [0, {len(index)}): min {a.min()}, max {a.max()}")
             return a.astype(np.int32)
         flat = [index.get(_as_str(s), 1) for s in a.reshape(-1)]
         return np.asarray(flat, np.int32).reshape(a.shape)
@@ -58,6 +62,10 @@ class Tokenization(Layer):
         The one-hot category matrix of the reference (tokenizers.py:72) is never materialised:
         the loss kernels gather by id."""
         category, attributes = inputs
+        if isinstance(category, torch.Tensor) and category.is_cuda:
+            # ids already resident in HBM: range check + multi-hot scatter on the device, no host hop
+            from . import kernels as K
+            return K.tokens_prepare(category, attributes, self._vocab_size_category, self._vocab_size_attributes)
         cat = self.lookup(category, self._cat_index)
         if cat.ndim == 3:
             cat = cat[..., 0]                           # tf.squeeze(axis=2)

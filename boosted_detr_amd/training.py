@@ -72,8 +72,15 @@ class SGD:
         lr = self.learning_rate
         return float(lr(self.iterations)) if callable(lr) else float(lr)
 
+    def release(self) -> None:
+        """Detach the variables of the previous build from this optimizer's flat buffer."""
+        for v in getattr(self, "vars", []):
+            if getattr(v, "_grad_flat", None) is getattr(self, "flat_grad", None):
+                v.grad_buf, v._grad_flat = None, None
+
     def build(self, variables: List[Variable]) -> None:
         dev = device()
+        self.release()
         self.vars = list(variables)
         sizes = [v.value.numel() for v in self.vars]
         offs = np.concatenate([[0], np.cumsum([(s + 3) // 4 * 4 for s in sizes])])      # 16-byte aligned slots
@@ -99,7 +106,7 @@ class SGD:
         self.d_norms = torch.empty(len(self.vars), dtype=torch.float32, device=dev)
         self.d_lr = torch.zeros(1, dtype=torch.float32, device=dev)
         for v, gv in zip(self.vars, self.grad_views):
-            v.grad_buf = gv
+            v.grad_buf, v._grad_flat = gv, self.flat_grad
         self._built_for = [id(v) for v in self.vars]
 
     def stage_gradients(self, variables: List[Variable]) -> None:
@@ -150,10 +157,16 @@ class DataParallel:
             h.wait()
 
     def broadcast_variables(self, variables: List[Variable]) -> None:
+        """Replicas start from rank 0's values (weights AND moving statistics), like MirroredStrategy's mirrored
+        variables (parameters.py:74)."""
         if self.world == 1:
             return
         for v in variables:
             self.dist.broadcast(v.value, src=0)
+
+    def barrier(self) -> None:
+        if self.world > 1:
+            self.dist.barrier()
 
 
 # ----------------------------------------------------------------------------------------
@@ -182,7 +195,11 @@ class ModelCheckpoint(Callback):
 
     def on_epoch_end(self, epoch, logs=None):
         path = self.filepath.format(epoch=epoch + 1, **(logs or {}))
-        self.model.save_weights(path)
+        dp = getattr(self.model, "_dp", None)
+        if dp is None or dp.rank == 0:              # replicas hold identical weights: one writer, the others wait
+            self.model.save_weights(path)
+        if dp is not None:
+            dp.barrier()
 
 
 class TensorBoard(Callback):
@@ -242,23 +259,34 @@ class Model(Layer):
     def compile(self, optimizer=None, **kwargs) -> None:
         if kwargs.get("loss") is not None:
             raise NotImplementedError("the reference compiles without a loss (losses are built into the model, model.py:208)")
+        if self.optimizer is not None and self.optimizer is not optimizer:
+            self.optimizer.release()                # no variable keeps a slice of the retired optimizer's gradient buffer
+        for v in self.variables:
+            if optimizer is None or getattr(v, "_grad_flat", None) is not getattr(optimizer, "flat_grad", None):
+                v.grad_buf, v._grad_flat = None, None
         self.optimizer = optimizer
 
     def distribute(self) -> "Model":
         """Enable data parallelism over the initialised torch.distributed (RCCL) process group."""
         self._dp = DataParallel()
         self.loss_fn.loss_scale = 1.0 / self._dp.world     # S14: per-replica loss scaled by 1/num_replicas
+        self._dp_synced = False                            # variables are broadcast from rank 0 once they exist (first step)
         return self
 
     # -- one step ----------------------------------------------------------------------------
     def forward_backward(self, data: dict):
         """forward + matcher + loss + backward.  Leaves gradients in Variable.grad."""
         self._step_losses, self._loss_roots, self._step_metrics = [], [], {}
-        ops.set_dropout_seed(0x5EED + self.steps_done)
+        # per-step, per-replica dropout masks: replicas draw independent masks (as under MirroredStrategy)
+        rank = self._dp.rank if self._dp is not None else 0
+        ops.set_dropout_seed(0x5EED + self.steps_done + 0x9E3779B1 * rank)
         for v in self.variables:
             v.reset_grad()
+        live = None
         if self.optimizer is not None and getattr(self.optimizer, "flat_grad", None) is not None:
-            self.optimizer.flat_grad.zero_()     # ONE memset for all gradients (split-K GEMMs accumulate into zeros)
+            live = self.optimizer.flat_grad
+            live.zero_()                         # ONE memset for all gradients (split-K GEMMs accumulate into zeros)
+        ops.set_live_flat_grad(live)             # in-place gradient sinks are valid for slices of THIS buffer only
         tape = Tape()
         prev = K.set_launch_stream(torch.cuda.current_stream().cuda_stream)     # pin the launch stream for the step
         try:
@@ -268,13 +296,21 @@ class Model(Layer):
                 tape.backward({id(t): t for t in self._loss_roots})     # parameter gradients land in Variable.grad (ops.GradSink)
         finally:
             K.set_launch_stream(prev)
+            ops.set_live_flat_grad(None)
         join_side_stream()                                      # weight-gradient GEMMs ran on the side stream
         return y_pred
 
     def train_step(self, data: dict) -> Dict[str, torch.Tensor]:
         if self.optimizer is None:
             raise RuntimeError("call compile(optimizer=...) before fit/train_step")
+        if self._dp is not None and not getattr(self, "_dp_synced", True) and self.built_variables():
+            self._dp.broadcast_variables(self.variables)
+            self._dp_synced = True
         self.forward_backward(data)
+        if self._dp is not None and not getattr(self, "_dp_synced", True):
+            # build-by-first-call just created the variables: replicas adopt rank 0's initial values before any update
+            self._dp.broadcast_variables(self.variables)
+            self._dp_synced = True
         if self.validate_matching:
             # scipy raises ValueError on NaN/-inf or infeasible cost matrices (the reference's
             # tf.numpy_function then fails the step); the GPU solver leaves such rows at -1.
@@ -287,6 +323,10 @@ class Model(Layer):
         self.optimizer.apply_gradients()
         self.steps_done += 1
         return self.step_logs()
+
+    def built_variables(self) -> bool:
+        """True once build-by-first-call has created every variable (the loss layer is the last one to run)."""
+        return bool(self.variables) and getattr(self.loss_fn, "last_match", None) is not None
 
     def test_step(self, data):
         return self.train_step(data)        # model.py:235-236: validation also trains (quirk kept)
@@ -361,13 +401,22 @@ class Model(Layer):
         if not filepath.endswith(".safetensors"):
             filepath += ".safetensors"
         os.makedirs(os.path.dirname(os.path.abspath(filepath)), exist_ok=True)
-        save_file({k: np.ascontiguousarray(v) for k, v in self.get_weights_dict().items()}, filepath)
+        meta = {"steps_done": str(self.steps_done),
+                "optimizer_iterations": str(self.optimizer.iterations if self.optimizer is not None else 0)}
+        save_file({k: np.ascontiguousarray(v) for k, v in self.get_weights_dict().items()}, filepath, metadata=meta)
 
     def load_weights(self, filepath: str) -> None:
         from safetensors.numpy import load_file
         if not filepath.endswith(".safetensors"):
             filepath += ".safetensors"
         self.set_weights_dict(load_file(filepath))
+        from safetensors import safe_open
+        with safe_open(filepath, framework="np") as f:
+            meta = f.metadata() or {}
+        # the step counter seeds the dropout masks and drives the learning-rate schedule: a resumed run continues both
+        self.steps_done = int(meta.get("steps_done", self.steps_done))
+        if self.optimizer is not None and "optimizer_iterations" in meta:
+            self.optimizer.iterations = int(meta["optimizer_iterations"])
 
     def summary(self) -> str:
         lines = [f'Model: "{self.name}"', "-" * 96]

@@ -79,6 +79,14 @@ enum { BDETR_ACT_NONE = 0, BDETR_ACT_RELU = 1, BDETR_ACT_TANH = 2 };
  * ---------------------------------------------------------------------- */
 int bdetr_image_prep(const float* in, int B, int h, int w, float* out, int H, int W, void* stream);
 
+/* Targets that are already tokenised and resident in HBM - tokenizers.py:40-82 minus the StringLookup
+ * (strings never reach the device): category ids [rows] are range-checked against C, the attribute id
+ * slots [rows][slots] become the multi-hot matrix [rows][A] (tf.one_hot + reduce_max over the slot axis,
+ * tokenizers.py:72-82; <PAD> slots set bit 0).  An id outside its vocabulary maps to 1 (<OOV>), as
+ * StringLookup maps an unknown string.  rows = B*M. */
+int bdetr_tokens_prepare(const int* cat_ids, const int* att_ids, int64_t rows, int slots, int C, int A,
+                         int* cat_out, float* att_hot, void* stream);
+
 /* Input-step augmentations (pipeline.py:274-341): per image, bilinear down-size to
  * (new_h,new_w), place at (off_h,off_w) on a zero canvas of the original size, then tf.image
  * adjust_contrast / adjust_brightness / adjust_saturation with the given factors.  in/out: [B,H,W,3]

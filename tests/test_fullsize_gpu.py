@@ -59,6 +59,9 @@ def test_config2_batch2_matches_oracle(cuda):
         g, w = v.grad_numpy().astype(np.float64).ravel(), grads[name].astype(np.float64).ravel()
         cos = g @ w / (np.linalg.norm(g) * np.linalg.norm(w))
         assert cos > 0.995, (name, cos)
+    # every trainable tensor against the fp64 oracle (relative L2, next to the fp32 oracle's own error)
+    from test_model_gpu import check_grads
+    check_grads(model, cfg, params, batch)
 
 
 def test_config2_batch16_properties(cuda):

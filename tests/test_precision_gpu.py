@@ -1,7 +1,12 @@
-"""The three arithmetic policies of the conv/GEMM family (include/bdetr.h: BDETR_GEMM_FP32 / BF16X3 / MIXED)
-against fp64 products.  Tolerances: exact-fp32 MFMA 2e-5 x max|ref| (fp32 round-off over the sum), split-bf16
-6e-5 x max|ref| (2^-18 per product).  Every operand flavour (r-/x-contiguous, im2col patch gather, flipped
-taps), the 64x64 and 128x128 split tiles, split-K atomics and the grouped launch run in split mode here."""
+"""The arithmetic policies of the conv/GEMM family (include/bdetr.h: BDETR_GEMM_FP32 / BF16X3 / SPLIT; MIXED is
+covered by test_default_policy_is_mixed) against fp64 products.  Tolerances: exact-fp32 MFMA and split-fp16 forward
+products 2e-5 x max|ref| (fp32-grade round-off over the sum), split-bf16 6e-5 x max|ref| (2^-18 per product).
+
+Which kernel variant a shape reaches depends on the tile chooser (csrc/igemm.hip choose_tile): the 128x128 split
+tiles are only picked when the grid still fills the chip, i.e. at the benchmark's batch-16 shapes.  BIG_CONVS /
+BIG_LINEARS below are sized to cross that threshold, and test_bench_step_variants_are_all_oracle_tested asserts
+that EVERY (arithmetic, loaders, layouts, tile) tuple a config-2 batch-16 training step launches is also launched -
+and compared with an fp64 reference - by the kernel-level cases of this file."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -9,10 +14,21 @@ import torch.nn.functional as F
 from test_kernels_gpu import close, dev, rnd
 
 pytestmark = pytest.mark.gpu
-TOL = {"fp32": 2e-5, "bf16x3": 6e-5}
+TOL = {"fp32": 2e-5, "bf16x3": 6e-5, "split": 6e-5}          # gradient products (and everything under bf16x3)
+TOL_FWD = {"fp32": 2e-5, "bf16x3": 6e-5, "split": 2e-5}      # forward products: split = fp16x3, fp32-grade
+
+LINEARS = [(300, 256, 256), (6400, 256, 1024), (1600, 1024, 256), (130, 52, 48), (4000, 64, 64), (25600, 128, 512)]
+BIG_LINEARS = [(102400, 256, 128), (25600, 1024, 256), (6400, 2048, 512)]
+CONVS = [(2, 20, 20, 64, 64, 3, 1, 1), (2, 20, 20, 256, 128, 1, 2, 0), (1, 9, 11, 128, 32, 3, 1, 1),
+         (3, 7, 7, 512, 2048, 1, 1, 0), (4, 40, 40, 256, 256, 3, 1, 1), (2, 32, 32, 4, 64, 7, 2, 3)]
+# shapes that reach the 128x128 split tiles (>= 0.75 workgroups per CU): the batch-16 3x3 convolutions of ResNet
+# stages 3-5, a batch-16 stage-2 1x1, a strided 1x1 and the batch-16 stem
+BIG_CONVS = [(8, 80, 80, 128, 128, 3, 1, 1), (16, 40, 40, 256, 256, 3, 1, 1), (16, 20, 20, 512, 512, 3, 1, 1),
+             (4, 80, 80, 256, 512, 1, 1, 0), (16, 80, 80, 512, 256, 1, 2, 0), (16, 160, 160, 64, 64, 3, 1, 1),
+             (4, 320, 320, 4, 64, 7, 2, 3)]
 
 
-@pytest.fixture(params=["fp32", "bf16x3"])
+@pytest.fixture(params=["fp32", "bf16x3", "split"])
 def mode(request, cuda):
     from boosted_detr_amd import kernels as k
     prev = k.set_gemm_precision(request.param)
@@ -34,18 +50,15 @@ def test_default_policy_is_mixed(cuda):
     assert e_fwd < 1.5e-6 and 1.5e-6 < e_bwd < 1e-5, (float(e_fwd), float(e_bwd))
 
 
-@pytest.mark.parametrize("M,K,O", [(300, 256, 256), (6400, 256, 1024), (1600, 1024, 256), (130, 52, 48), (4000, 64, 64), (25600, 128, 512)])
-def test_linear_all_flavours(mode, M, K, O):
+def linear_case(mode, M, K, O):
     from boosted_detr_amd import kernels as k
     x, w, b, dy = rnd(M, K, seed=1), rnd(O, K, seed=2, scale=K ** -0.5), rnd(O, seed=3), rnd(M, O, seed=4)
-    close(k.linear_fwd(dev(x), dev(w), dev(b), 1), (x.double() @ w.double().T + b.double()).relu(), rtol=TOL[mode])
+    close(k.linear_fwd(dev(x), dev(w), dev(b), 1), (x.double() @ w.double().T + b.double()).relu(), rtol=TOL_FWD[mode])
     close(k.linear_bwd_data(dev(dy), dev(w)), dy.double() @ w.double(), rtol=TOL[mode])
     close(k.linear_bwd_weight(dev(dy), dev(x)), dy.double().T @ x.double(), rtol=TOL[mode])
 
 
-@pytest.mark.parametrize("N,H,W,C,K,R,stride,pad", [(2, 20, 20, 64, 64, 3, 1, 1), (2, 20, 20, 256, 128, 1, 2, 0), (1, 9, 11, 128, 32, 3, 1, 1),
-                                                    (3, 7, 7, 512, 2048, 1, 1, 0), (4, 40, 40, 256, 256, 3, 1, 1), (2, 32, 32, 4, 64, 7, 2, 3)])
-def test_conv_all_flavours(mode, N, H, W, C, K, R, stride, pad):
+def conv_case(mode, N, H, W, C, K, R, stride, pad):
     from boosted_detr_amd import kernels as k
     x, w, b = rnd(N, H, W, C, seed=1), rnd(K, R, R, C, seed=2, scale=(R * R * C) ** -0.5), rnd(K, seed=3)
     g = k.ConvGeom(N, H, W, C, K, R, R, stride, pad)
@@ -53,27 +66,104 @@ def test_conv_all_flavours(mode, N, H, W, C, K, R, stride, pad):
     xt = x.double().permute(0, 3, 1, 2).requires_grad_(True)
     wt = w.double().permute(0, 3, 1, 2).requires_grad_(True)
     ref = F.conv2d(xt, wt, b.double(), stride=stride, padding=pad)
-    close(y, ref.permute(0, 2, 3, 1), rtol=TOL[mode])
+    close(y, ref.permute(0, 2, 3, 1), rtol=TOL_FWD[mode])
     close(ps.sum(0), ref.permute(0, 2, 3, 1).reshape(-1, K).sum(0), rtol=1e-4)
     dy = rnd(*ref.shape, seed=4).double()
     ref.backward(dy)
     dyn = dy.permute(0, 2, 3, 1).float()
     if R != 7:
         close(k.conv2d_bwd_data(dev(dyn), dev(w), g), xt.grad.permute(0, 2, 3, 1), rtol=TOL[mode])
+        base = rnd(N, H, W, C, seed=9)
+        dx2 = dev(base)
+        k.conv2d_bwd_data(dev(dyn), dev(w), g, dx=dx2, accumulate=True)       # the residual-merge epilogue
+        close(dx2, base.double() + xt.grad.permute(0, 2, 3, 1), rtol=TOL[mode])
     close(k.conv2d_bwd_weight(dev(x), dev(dyn), g), wt.grad.permute(0, 2, 3, 1), rtol=max(TOL[mode], 5e-5))
 
 
-def test_grouped_launch(mode):
+@pytest.mark.parametrize("M,K,O", LINEARS + BIG_LINEARS)
+def test_linear_all_flavours(mode, M, K, O):
+    linear_case(mode, M, K, O)
+
+
+@pytest.mark.parametrize("N,H,W,C,K,R,stride,pad", CONVS + BIG_CONVS)
+def test_conv_all_flavours(mode, N, H, W, C, K, R, stride, pad):
+    conv_case(mode, N, H, W, C, K, R, stride, pad)
+
+
+def _prof_tuples(path):
+    """{(kind, bm, bn)} of the igemm launches recorded since bdetr_prof_enable(1); kind = arithmetic * 10000 +
+    loader/layout code of both operands (csrc/igemm.hip launch_cfg)."""
+    import csv
+    import torch as _t
+    from boosted_detr_amd import _lib
+    _t.cuda.synchronize()
+    _lib.check(_lib.lib().bdetr_prof_dump(path.encode()), "prof_dump")
+    with open(path) as f:
+        return {(int(r["kind"]), int(r["bm"]), int(r["bn"])) for r in csv.DictReader(f)}
+
+
+def test_bench_step_variants_are_all_oracle_tested(cuda, tmp_path):
+    """Coverage of the kernels the benchmark actually runs: every igemm variant launched by one BASELINE configs[1]
+    training step at the bench's batch 16 must also be launched - and compared with an fp64 reference, in this very
+    test - by the kernel-level cases above under the same 'split' policy."""
+    import os
+    import sys
+    from boosted_detr_amd import _lib, engine
+    from boosted_detr_amd import kernels as k
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    L = _lib.lib()
+    side_was = engine._SIDE["enabled"]
+    engine.set_side_stream_enabled(False)            # hipEvent brackets on one stream
+    try:
+        with k.gemm_precision("split"):
+            L.bdetr_prof_enable(1)
+            for shp in LINEARS + BIG_LINEARS:
+                linear_case("split", *shp)
+            for shp in CONVS + BIG_CONVS:
+                conv_case("split", *shp)
+            _grouped_case("split")
+            tested = _prof_tuples(str(tmp_path / "tested.csv"))
+        args = type("A", (), dict(model="detr", fashionpedia=False, backbone="ResNet", image=640, image_w=0, layers=6, queries=100,
+                                  learners=3, batch=16))()
+        model = bench.build_model(args)
+        assert model.train_gemm_precision == "split"
+        host = bench.make_batch(16, 640, 640, 100, 82, seed=1234)
+        model.train_step(host)                      # build-by-first-call (not recorded: first-step staging differs)
+        L.bdetr_prof_enable(1)
+        model.train_step(host)
+        launched = _prof_tuples(str(tmp_path / "bench.csv"))
+    finally:
+        L.bdetr_prof_enable(0)
+        engine.set_side_stream_enabled(side_was)
+    assert len(launched) >= 8
+    missing = sorted(launched - tested)
+    assert not missing, f"bench-step igemm variants never compared with an oracle (kind, bm, bn): {missing}; tested: {sorted(tested)}"
+
+
+def _grouped_case(mode):
     from boosted_detr_amd import kernels as k
     xs = [rnd(m, 256, seed=m) for m in (400, 400, 100)]
     ws = [rnd(256, 256, seed=7 + i, scale=1 / 16) for i in range(3)]
     bs = [rnd(256, seed=11 + i) for i in range(3)]
     ys = k.linear_fwd_group([dev(x) for x in xs], [dev(w) for w in ws], [dev(b) for b in bs])
     for y, x, w, b in zip(ys, xs, ws, bs):
-        close(y, x.double() @ w.double().T + b.double(), rtol=TOL[mode])
+        close(y, x.double() @ w.double().T + b.double(), rtol=TOL_FWD[mode])
     dxs = k.linear_bwd_data_group([dev(x) for x in xs], [dev(w) for w in ws])
     for dx, x, w in zip(dxs, xs, ws):
         close(dx, x.double() @ w.double(), rtol=TOL[mode])
+    # the encoder's shapes (6400-row q/k/v projections of a batch-16 step)
+    xs = [rnd(6400, 256, seed=20 + i) for i in range(3)]
+    ys = k.linear_fwd_group([dev(x) for x in xs], [dev(w) for w in ws], [dev(b) for b in bs])
+    for y, x, w, b in zip(ys, xs, ws, bs):
+        close(y, x.double() @ w.double().T + b.double(), rtol=TOL_FWD[mode])
+    dxs = k.linear_bwd_data_group([dev(x) for x in xs], [dev(w) for w in ws])
+    for dx, x, w in zip(dxs, xs, ws):
+        close(dx, x.double() @ w.double(), rtol=TOL[mode])
+
+
+def test_grouped_launch(mode):
+    _grouped_case(mode)
 
 
 def test_training_step_runs_split_and_restores_policy(cuda):

@@ -163,3 +163,62 @@ def test_dropout_is_seeded_and_changes_per_step(cuda):
     model.steps_done += 1
     c = [t.cpu().numpy() for t in model.forward_backward(batch)]
     assert not np.array_equal(a[0], c[0])
+
+
+def _grads_after_one_step(model, batch):
+    model.forward_backward(batch)
+    tv = model.trainable_variables
+    model.optimizer.stage_gradients(tv)
+    torch.cuda.synchronize()
+    return {v.name: v.grad.detach().cpu().numpy().copy() for v in tv}
+
+
+def test_recompile_and_unfreeze_do_not_reuse_stale_gradient_slices(cuda):
+    """compile(new optimizer) between training blocks (Boosted_DETR_COCO.ipynb cells 26/30) and a freeze -> train ->
+    unfreeze cycle leave some variables with a slice of a retired flat gradient buffer that still holds an earlier
+    step's gradients; the in-place sinks (split-K atomics accumulate!) must not write there.  The first step after
+    either event has to produce the gradients a freshly built model produces for the same weights and batch."""
+    from boosted_detr_amd.training import SGD
+    from oracle import detr_oracle as O
+    cfg, batch = small_batch()
+    _, batch2 = small_batch(seed=21)
+    params = O.make_params(cfg, seed=1)
+
+    def fresh():
+        m = small_model()
+        m.compile(optimizer=SGD(1e-3, momentum=0.9, nesterov=True, clipnorm=0.1))
+        m.forward_backward(batch)
+        m.set_weights_dict(params)
+        return m
+
+    def same(a, b):
+        assert a.keys() == b.keys()
+        for k in a:
+            scale = np.abs(b[k]).max() + 1e-30
+            assert np.abs(a[k] - b[k]).max() <= 1e-5 * scale, k      # split-K atomics: order-dependent last bits only
+
+    want = _grads_after_one_step(fresh(), batch)
+
+    # (1) train a step on another batch (the flat buffer now holds ITS gradients), recompile, first step
+    m = fresh()
+    m.train_step(batch2)
+    m.set_weights_dict(params)
+    old_flat = m.optimizer.flat_grad
+    m.compile(optimizer=SGD(1e-3, momentum=0.9, nesterov=True, clipnorm=0.1))
+    assert all(v.grad_buf is None for v in m.variables)
+    same(_grads_after_one_step(m, batch), want)
+    assert m.optimizer.flat_grad is not old_flat
+
+    # (2) freeze the backbone, train, unfreeze: the backbone's slices belong to the pre-freeze buffer
+    m = fresh()
+    m.train_step(batch2)
+    m.EncoderBackbone.trainable = False
+    m.train_step(batch2)
+    frozen_names = {v.name for v in m.EncoderBackbone.variables}
+    assert all(v.grad_buf is None for v in m.variables if v.name in frozen_names)
+    m.EncoderBackbone.trainable = True
+    m.set_weights_dict(params)
+    for v in m.variables:                                    # moving statistics moved during the extra steps
+        if not v.trainable:
+            v.assign(params[v.name])
+    same(_grads_after_one_step(m, batch), want)
