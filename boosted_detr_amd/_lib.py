@@ -67,6 +67,15 @@ SIGNATURES = {
     "bdetr_conv2d_bwd_data": (I, [P, P, P, C.POINTER(ConvDesc), I, P]),
     "bdetr_conv2d_bwd_weight": (I, [P, P, P, C.POINTER(ConvDesc), I, P]),
     "bdetr_conv2d_bwd_weight_splitk": (I, [C.POINTER(ConvDesc)]),
+    "bdetr_p16_supported": (I, [C.POINTER(ConvDesc)]),
+    "bdetr_p16_pack": (I, [P, L, P, P, P, P]),
+    "bdetr_p16_unpack": (I, [P, I, L, P, P]),
+    "bdetr_p16_pack_conv_weights": (I, [P, I, I, I, I, P, P, P, P]),
+    "bdetr_p16_conv2d_fwd_stat_chunks": (I, [C.POINTER(ConvDesc)]),
+    "bdetr_p16_conv2d_fwd": (I, [P, P, P, P, C.POINTER(ConvDesc), I, P, P, P]),
+    "bdetr_p16_conv2d_bwd_data": (I, [P, P, P, C.POINTER(ConvDesc), I, P]),
+    "bdetr_p16_conv2d_bwd_weight_splitk": (I, [C.POINTER(ConvDesc)]),
+    "bdetr_p16_conv2d_bwd_weight": (I, [P, P, P, C.POINTER(ConvDesc), I, P]),
     "bdetr_gemm": (I, [C.POINTER(GemmDesc), P]),
     "bdetr_gemm_grouped": (I, [C.POINTER(GemmDesc), I, P]),
     "bdetr_colsum_chunks": (I, [L]),

@@ -16,7 +16,7 @@ from pathlib import Path
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB = CSRC / "libbdetr.so"
 OBJ_DIR = CSRC / "_obj"
-SOURCES = ["common.cpp", "igemm.hip", "attention.hip", "augment.hip", "norm.hip", "elementwise.hip", "matcher.hip", "optim.hip"]
+SOURCES = ["common.cpp", "igemm.hip", "sgemm.hip", "p16.hip", "attention.hip", "augment.hip", "norm.hip", "elementwise.hip", "matcher.hip", "optim.hip"]
 ARCH = "gfx950"
 COMMON_FLAGS = ["-O3", "-fPIC", f"--offload-arch={ARCH}", "-std=c++17", "-Wall", "-Wno-unused-function"]
 # the matcher must not contract a*b+c into fma (scipy / numpy evaluate unfused); see matcher.hip
@@ -39,7 +39,7 @@ def _digest(paths) -> str:
 
 
 def build(force: bool = False, verbose: bool = True) -> Path:
-    deps = [CSRC / s for s in SOURCES] + [CSRC / "common.h", CSRC.parent.parent / "include" / "bdetr.h"]
+    deps = [CSRC / s for s in SOURCES] + [CSRC / "common.h", CSRC / "gemm_common.h", CSRC / "p16.h", CSRC.parent.parent / "include" / "bdetr.h"]
     stamp = CSRC / "_obj" / "stamp"
     dig = _digest(deps)
     if not force and LIB.exists() and stamp.exists() and stamp.read_text() == dig:
@@ -57,7 +57,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
         subprocess.run(cmd, check=True)
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
+    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         objs = list(ex.map(compile_one, SOURCES))
     cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *map(str, objs), "-o", str(LIB)]
     if verbose:

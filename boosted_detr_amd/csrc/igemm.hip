@@ -14,12 +14,14 @@
 // Replaces: Keras Conv2D / Dense / tf.linalg.matmul and their autodiff
 // (backbone.py:37-38,76-78; transformers.py:41-48,62-65,86,97,101,174-177;
 //  prediction_heads.py:40-43,106-110,175-179).
-#include "common.h"
+#include "gemm_common.h"
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
 #include <utility>
 #include <vector>
+
+using namespace bdgemm;
 
 namespace {
 
@@ -43,7 +45,6 @@ constexpr int NTHREADS = 256;
 // in with 2^-11 in the epilogue.  Operand magnitudes must stay below 65504 (beyond that the hi half is
 // inf and the output NaN - loud, not silent); gradients, whose range is unbounded, never take this path.
 constexpr int SLD = 36;      // dwords per LDS row in split mode
-enum { AR_FP32 = 0, AR_BF16X3 = 1, AR_FP16X3 = 2 };
 constexpr float LO_SCALE = 2048.f;
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -167,25 +168,6 @@ struct WFlipLoader {
 // ----------------------------------------------------------------------------------------
 // epilogue / problem description
 // ----------------------------------------------------------------------------------------
-enum { ST_STORE = 0, ST_ACCUM = 1, ST_ATOMIC = 2 };
-
-struct GemmParams {
-    int I, J, R;
-    int nb1;                 // batch index z = b0*nb1 + b1 (when splitk == 1)
-    int splitk, r_chunk;     // split of the r range over gridDim.z (r_chunk multiple of BK)
-    int tiles_i, tiles_j;
-    float* c; int64_t ldc, sc0, sc1;
-    const float* bias; float alpha; int act; int mode;
-    float* stat_sum; float* stat_sq;    // [tiles_i*WM][J] partial column sums (may be null)
-    int vec_store;                      // C rows are 16-byte aligned and J % 4 == 0: LDS-transposed float4 stores
-    int rowmap;                         // scatter C rows through a strided-pixel map (conv s>1 bwd-data)
-    int rm_OW, rm_OHOW, rm_H, rm_W, rm_stride;
-    // grouped launch (dense operands only): blockIdx.z selects one of up to 4 independent problems that
-    // share J, R and the epilogue flags but have their own pointers and row count (Q/K/V projections)
-    int ngroups;
-    const float* ga[4]; const float* gb[4]; float* gc[4]; const float* gbias[4]; int gI[4];
-};
-
 template <int BX, bool RC>
 struct TileGeom {
     static constexpr int LDS_FLOATS = RC ? BX * (BK + RPAD) : BK * BX;
@@ -193,12 +175,6 @@ struct TileGeom {
     static constexpr int VPR = RC ? BK / 4 : BX / 4;            // vectors per natural row
     static constexpr int LDS_LD = RC ? BK + RPAD : BX;
 };
-
-__device__ __forceinline__ float apply_act(float v, int act) {
-    if (act == BDETR_ACT_RELU) return fmaxf(v, 0.f);
-    if (act == BDETR_ACT_TANH) return tanhf(v);
-    return v;
-}
 
 template <int BM, int BN, int WM, int WN, class LA, bool A_RC, class LB, bool B_RC, int ARITH>
 __global__ __launch_bounds__(NTHREADS, 2)
@@ -228,13 +204,7 @@ void igemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
     // XCD-aware tile order: blocks that are dispatched to the same XCD (blockIdx % 8) get
     // consecutive logical tiles, and tile_j is the fast index, so one XCD's L2 sees the same
     // A rows (the expensive im2col gather) from neighbouring workgroups.
-    const int nwg = g.tiles_i * g.tiles_j;
-    int wg;
-    {
-        const int bid = blockIdx.x;
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
+    const int wg = xcd_tile(blockIdx.x, g.tiles_i * g.tiles_j);
     const int tile_i = wg / g.tiles_j, tile_j = wg - tile_i * g.tiles_j;
     const int i0 = tile_i * BM, j0 = tile_j * BN;
 
@@ -486,13 +456,6 @@ void igemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
     }
 
     // ---------------- epilogue ----------------
-    float* cbase = g.c + (int64_t)b0 * g.sc0 + (int64_t)b1 * g.sc1;
-    auto out_row = [&](int i) -> int64_t {
-        if (!g.rowmap) return i;
-        int n = i / g.rm_OHOW; int rem = i - n * g.rm_OHOW;
-        int oh = rem / g.rm_OW; int ow = rem - oh * g.rm_OW;
-        return ((int64_t)n * g.rm_H + (int64_t)oh * g.rm_stride) * g.rm_W + (int64_t)ow * g.rm_stride;
-    };
     if constexpr (ARITH == AR_FP16X3) {
 #pragma unroll
         for (int a = 0; a < TM; ++a)
@@ -501,81 +464,7 @@ void igemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[a][b][e] += acc2[a][b][e] * (1.f / LO_SCALE);
     }
-    // bias + activation in registers, BN partial statistics from registers
-#pragma unroll
-    for (int b = 0; b < TN; ++b) {
-        const int j = j0 + wn * WTN + b * 32 + li;
-        const bool jok = j < g.J;
-        const float bias = (g.bias != nullptr && jok) ? g.bias[j] : 0.f;
-        float csum = 0.f, csq = 0.f;
-#pragma unroll
-        for (int a = 0; a < TM; ++a) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int i = i0 + wm * WTM + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                const float v = apply_act(g.alpha * acc[a][b][e] + bias, g.act);
-                acc[a][b][e] = v;
-                if (i < g.I && jok) { csum += v; csq += v * v; }
-            }
-        }
-        if (g.stat_sum != nullptr) {
-            csum += __shfl_xor(csum, 32, 64);
-            csq += __shfl_xor(csq, 32, 64);
-            if (lh == 0 && jok) {
-                const int64_t chunk = (int64_t)tile_i * WM + wm;
-                g.stat_sum[chunk * g.J + j] = csum;
-                g.stat_sq[chunk * g.J + j] = csq;
-            }
-        }
-    }
-
-    if (g.vec_store && g.mode != ST_ATOMIC) {
-        // Transpose the tile through LDS (the staging buffers are free after the last barrier) so that
-        // every lane stores 16 contiguous bytes: whole 256-byte (BN=64) rows per 16 lanes instead of
-        // 4-byte stores in 128-byte segments - 4x fewer store instructions, full-line writes.
-        constexpr int CLD = (BM * (BN + 4) <= 2 * STAGE_FLOATS) ? BN + 4 : BN;
-        static_assert(BM * CLD <= 2 * STAGE_FLOATS, "epilogue tile must fit in the staging LDS");
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int b = 0; b < TN; ++b)
-#pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    lds[(wm * WTM + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * CLD + wn * WTN + b * 32 + li] = acc[a][b][e];
-        __syncthreads();
-        constexpr int V_PER_ROW = BN / 4;
-#pragma unroll
-        for (int v = tid; v < BM * V_PER_ROW; v += NTHREADS) {
-            const int r = v / V_PER_ROW, c4 = v - r * V_PER_ROW;
-            const int i = i0 + r, j = j0 + 4 * c4;
-            if (i < g.I && j < g.J) {
-                f32x4 val = *reinterpret_cast<const f32x4*>(lds + r * CLD + 4 * c4);
-                f32x4* dst = reinterpret_cast<f32x4*>(cbase + out_row(i) * g.ldc + j);
-                if (g.mode == ST_ACCUM) val += *dst;
-                *dst = val;
-            }
-        }
-        return;
-    }
-#pragma unroll
-    for (int b = 0; b < TN; ++b) {
-        const int j = j0 + wn * WTN + b * 32 + li;
-        if (j >= g.J) continue;
-#pragma unroll
-        for (int a = 0; a < TM; ++a) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int i = i0 + wm * WTM + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (i < g.I) {
-                    float* dst = cbase + out_row(i) * g.ldc + j;
-                    const float v = acc[a][b][e];
-                    if (g.mode == ST_STORE) *dst = v;
-                    else if (g.mode == ST_ACCUM) *dst += v;
-                    else atomicAdd(dst, v);
-                }
-            }
-        }
-    }
+    gemm_epilogue<BM, BN, WM, WN, NTHREADS, 2 * STAGE_FLOATS>(acc, g, lds, tile_i, i0, j0, g.c + (int64_t)b0 * g.sc0 + (int64_t)b1 * g.sc1);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -583,6 +472,9 @@ void igemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
 // ----------------------------------------------------------------------------------------
 struct TileChoice { int bm, bn; };
 
+}  // namespace
+
+namespace bdgemm {
 int g_num_cus = 0;
 int num_cus() {
     if (g_num_cus == 0) {
@@ -592,11 +484,16 @@ int num_cus() {
     }
     return g_num_cus;
 }
+}  // namespace bdgemm
+
+namespace {
 
 // Pick the biggest tile that still gives every CU ~2 workgroups; small-J problems get narrow tiles.
 // BDETR_TILE=<bm>x<bn> (e.g. 128x64) forces a tile for tuning experiments.
 // GEMM arithmetic policy (include/bdetr.h): BDETR_GEMM_PRECISION=fp32|bf16x3|mixed sets the initial value,
 // bdetr_set_gemm_precision() changes it at run time.  use_split(grad) answers for one product.
+}  // namespace
+namespace bdgemm {
 int g_gemm_mode = -1;
 int gemm_mode() {
     if (g_gemm_mode < 0) {
@@ -606,6 +503,8 @@ int gemm_mode() {
     }
     return g_gemm_mode;
 }
+}  // namespace bdgemm
+namespace {
 int use_split(bool grad) {      // -> AR_* of one product
     switch (gemm_mode()) {
         case BDETR_GEMM_FP32:   return AR_FP32;
@@ -650,7 +549,6 @@ TileChoice choose_tile(int I, int J, int zdim, bool both_rc, bool split, bool pa
 // When enabled, every igemm launch is bracketed by two hipEvents recorded on the launch stream; the
 // host resolves the elapsed times after the timed region.  Events come from a pool that only grows.
 struct ProfRec { hipEvent_t e0, e1; double flops; int I, J, R, z, bm, bn, kind; };
-bool g_prof_on = false;
 std::vector<ProfRec> g_prof_recs;
 std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
 size_t g_prof_used = 0;
@@ -660,6 +558,9 @@ template <> struct LoaderId<PatchLoader> { static constexpr int v = 1; };
 template <> struct LoaderId<WFlipLoader> { static constexpr int v = 2; };
 template <> struct LoaderId<DenseLoader<1>> { static constexpr int v = 3; };
 
+}  // namespace
+namespace bdgemm {
+bool g_prof_on = false;
 void prof_begin(hipStream_t st, double flops, int I, int J, int R, int z, int bm, int bn, int kind) {
     if (g_prof_used == g_prof_pool.size()) {
         hipEvent_t a, b;
@@ -671,6 +572,8 @@ void prof_begin(hipStream_t st, double flops, int I, int J, int R, int z, int bm
     hipEventRecord(ev.first, st);
 }
 void prof_end(hipStream_t st) { hipEventRecord(g_prof_recs.back().e1, st); }
+}  // namespace bdgemm
+namespace {
 
 template <int BM, int BN, int WM, int WN, class LA, bool A_RC, class LB, bool B_RC, int ARITH = AR_FP32>
 int launch_cfg(const typename LA::Op& a, const typename LB::Op& b, GemmParams g, int zdim, hipStream_t st) {
@@ -712,8 +615,6 @@ int launch_any(const typename LA::Op& a, const typename LB::Op& b, GemmParams g,
     return launch_cfg<64, 64, 2, 2, LA, A_RC, LB, B_RC>(a, b, g, zdim, st);
 }
 
-bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-
 // The loaders address an operand with 32-bit byte offsets from its base (raw buffer loads, NUM_RECORDS):
 // one operand matrix / tensor must span less than 4 GB.  Larger batches shard over GPUs (or are split by the
 // caller); outputs are addressed with 64-bit pointers and have no such limit.
@@ -728,11 +629,6 @@ int stat_chunks(int I, int J) {
     return (int)cdiv64(I, t.bm) * wm;
 }
 
-void init_params(GemmParams& g) {
-    g = GemmParams{};
-    g.nb1 = 1; g.splitk = 1; g.alpha = 1.f; g.mode = ST_STORE;
-}
-
 }  // namespace
 
 // ----------------------------------------------------------------------------------------
@@ -742,7 +638,7 @@ extern "C" int bdetr_device_cus(void) { return num_cus(); }
 
 extern "C" int bdetr_set_gemm_precision(int mode) {
     BDETR_CHECK_ARG(mode >= BDETR_GEMM_FP32 && mode <= BDETR_GEMM_SPLIT, "bdetr_set_gemm_precision: unknown mode %d", mode);
-    g_gemm_mode = mode;
+    bdgemm::g_gemm_mode = mode;
     return 0;
 }
 extern "C" int bdetr_get_gemm_precision(void) { return gemm_mode(); }
@@ -784,7 +680,7 @@ static int prof_sum(int arith, double* total_ms, int64_t* launches, double* flop
 }
 extern "C" int bdetr_prof_read(double* total_ms, int64_t* launches, double* flops) { return prof_sum(-1, total_ms, launches, flops); }
 extern "C" int bdetr_prof_read_arith(int arith, double* total_ms, int64_t* launches, double* flops) {
-    BDETR_CHECK_ARG(arith >= AR_FP32 && arith <= AR_FP16X3, "bdetr_prof_read_arith: arith must be 0 (fp32), 1 (bf16x3) or 2 (fp16x3)");
+    BDETR_CHECK_ARG(arith >= AR_FP32 && arith <= AR_P16_BF16, "bdetr_prof_read_arith: arith must be 0 (fp32), 1 (bf16x3), 2 (fp16x3), 3 (pre-split f16) or 4 (pre-split bf16)");
     return prof_sum(arith, total_ms, launches, flops);
 }
 

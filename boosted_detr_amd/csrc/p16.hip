@@ -1,0 +1,73 @@
+// p16.hip - stand-alone producers of the P16 operand layout (sgemm.hip): fp32 -> f16 / bf16 pairs, the
+// per-step weight packs (forward copy + transposed, tap-flipped backward-data copy) and the inverse map.
+// The hot producers are fused: BatchNorm apply / BatchNorm backward write P16 directly (norm.hip).
+#include "p16.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void p16_pack_kernel(const float* __restrict__ x, int64_t n8, void* __restrict__ f16_out, void* __restrict__ bf16_out,
+                                                       int* __restrict__ overflow_flag) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const f32x4 a = reinterpret_cast<const f32x4*>(x)[2 * i], b = reinterpret_cast<const f32x4*>(x)[2 * i + 1];
+        const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        if (f16_out) {
+            p16_store8<true>(reinterpret_cast<char*>(f16_out) + i * 32, v);
+            if (overflow_flag && p16_f16_overflow(v)) *overflow_flag = 1;
+        }
+        if (bf16_out) p16_store8<false>(reinterpret_cast<char*>(bf16_out) + i * 32, v);
+    }
+}
+
+template <bool F16>
+__global__ __launch_bounds__(256) void p16_unpack_kernel(const void* __restrict__ p, int64_t n8, float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        float v[8];
+        p16_load8<F16>(reinterpret_cast<const char*>(p) + i * 32, v);
+        reinterpret_cast<f32x4*>(out)[2 * i] = f32x4{v[0], v[1], v[2], v[3]};
+        reinterpret_cast<f32x4*>(out)[2 * i + 1] = f32x4{v[4], v[5], v[6], v[7]};
+    }
+}
+
+// w [K][R][S][C] fp32 -> wt [C][R][S][K] P16-bf16 with the taps flipped: wt[c][r'][s'][k] = w[k][R-1-r'][S-1-s'][c].
+// One thread = one group of 8 k for one (c, tap); adjacent threads take adjacent c (coalesced reads).
+__global__ __launch_bounds__(256) void p16_pack_wt_kernel(const float* __restrict__ w, int K, int R, int S, int C, void* __restrict__ wt) {
+    const int64_t total = (int64_t)(K / 8) * R * S * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C); int64_t t = i / C;
+        const int tap = (int)(t % (R * S)); const int kg = (int)(t / (R * S));
+        const int r = tap / S, s = tap - r * S;
+        const int src_tap = (R - 1 - r) * S + (S - 1 - s);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = w[((int64_t)(kg * 8 + e) * R * S + src_tap) * C + c];
+        p16_store8<false>(reinterpret_cast<char*>(wt) + (((int64_t)c * R * S + tap) * K + kg * 8) * 4, v);
+    }
+}
+
+}  // namespace
+
+extern "C" int bdetr_p16_pack(const float* x, int64_t n, void* f16_out, void* bf16_out, int* overflow_flag, void* stream) {
+    BDETR_CHECK_ARG(x && n > 0 && n % 8 == 0 && (f16_out || bf16_out), "bdetr_p16_pack: bad arguments (n %% 8 == 0 required)");
+    hipLaunchKernelGGL(p16_pack_kernel, dim3(ew_grid(n / 8, 256, 2)), dim3(256), 0, (hipStream_t)stream, x, n / 8, f16_out, bf16_out, overflow_flag);
+    return bdetr_launch_status("p16_pack");
+}
+
+extern "C" int bdetr_p16_unpack(const void* p, int is_f16, int64_t n, float* out, void* stream) {
+    BDETR_CHECK_ARG(p && out && n > 0 && n % 8 == 0, "bdetr_p16_unpack: bad arguments (n %% 8 == 0 required)");
+    if (is_f16) hipLaunchKernelGGL((p16_unpack_kernel<true>), dim3(ew_grid(n / 8, 256, 2)), dim3(256), 0, (hipStream_t)stream, p, n / 8, out);
+    else        hipLaunchKernelGGL((p16_unpack_kernel<false>), dim3(ew_grid(n / 8, 256, 2)), dim3(256), 0, (hipStream_t)stream, p, n / 8, out);
+    return bdetr_launch_status("p16_unpack");
+}
+
+// Both operand copies of one conv / dense weight tensor w [K][R][S][C] (OHWI):
+//   w_f16   P16-f16  [K][R*S*C]        forward B operand
+//   wt_bf16 P16-bf16 [C][R*S][K]       backward-data B operand (transposed, taps flipped)
+// Either output may be null.
+extern "C" int bdetr_p16_pack_conv_weights(const float* w, int K, int R, int S, int C, void* w_f16, void* wt_bf16, int* overflow_flag, void* stream) {
+    BDETR_CHECK_ARG(w && K > 0 && R > 0 && S > 0 && C > 0 && K % 8 == 0 && C % 8 == 0, "bdetr_p16_pack_conv_weights: K and C must be multiples of 8");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n = (int64_t)K * R * S * C;
+    if (w_f16) hipLaunchKernelGGL(p16_pack_kernel, dim3(ew_grid(n / 8, 256, 2)), dim3(256), 0, st, w, n / 8, w_f16, (void*)nullptr, overflow_flag);
+    if (wt_bf16) hipLaunchKernelGGL(p16_pack_wt_kernel, dim3(ew_grid(n / 8, 256, 1)), dim3(256), 0, st, w, K, R, S, C, wt_bf16);
+    return bdetr_launch_status("p16_pack_conv_weights");
+}

@@ -1,0 +1,525 @@
+// sgemm.hip - MFMA GEMM / implicit-GEMM family over PRE-SPLIT operands for gfx950 (MI355X).
+//
+// igemm.hip reads fp32 operands, splits every element into hi/lo 16-bit halves in registers and writes the
+// halves to LDS: the global -> VGPR -> split VALU -> ds_write staging path, not the MFMA pipe, bounds it
+// (profiles/README.md, round 1).  Here the PRODUCER of a tensor (BatchNorm apply / BatchNorm backward /
+// the weight pack that follows the optimizer) writes the halves once, in the "P16" layout, and this kernel
+// moves them HBM -> LDS with `buffer_load_dwordx4 ... lds` (no VGPR round trip, no split arithmetic, no
+// ds_write) and feeds three v_mfma_f32_32x32x16_{f16,bf16} per product exactly like igemm.hip's split modes.
+//
+// P16 layout of a row-major [rows][C] matrix (C % 8 == 0), 4 bytes per element like fp32: every group of 8
+// consecutive elements is 32 bytes = [8 x hi (16 bit)] [8 x lo (16 bit)].
+//   f16 pair  (forward operands):   hi = f16(x),  lo = f16((x - hi) * 2^11)   (22 significant bits, |x| < 65504)
+//   bf16 pair (gradient operands):  hi = bf16(x), lo = bf16(x - hi)           (16 significant bits, fp32 range)
+// A 16-byte chunk is therefore 8 reduction elements of one half: exactly one lane's MFMA operand fragment when
+// the reduction index is the contiguous one ("RR": conv forward / backward-data, ds_read_b128), and a
+// 4-rows x 16-columns block for ds_read_b64_tr_b16 when it is the strided one ("XX": weight gradients, where the
+// reduction runs over pixels).
+//
+// Replaces: Keras Conv2D and its autodiff inside tf.keras.applications ResNet-50 (backbone.py:37-38,57).
+#include "gemm_common.h"
+#include <stdlib.h>
+#include <string.h>
+#include <type_traits>
+
+using namespace bdgemm;
+
+namespace {
+
+constexpr int BK = 32;                          // reduction depth of one LDS stage
+constexpr unsigned OOB = 0xFFFFFFF0u;           // byte offset beyond num_records: the load writes zeros
+constexpr unsigned NUM_RECORDS = 0xFFFFFF00u;   // operands must span < 4 GB (checked on the host)
+constexpr float LO_SCALE = 2048.f;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    void* q = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(q, 0, (int)NUM_RECORDS, 0x00020000);
+}
+
+// exact unsigned division by an invariant divisor d (1 <= d < 2^31) of n < 2^31: q = umulhi(n, mul) >> sh with
+// mul = floor(2^(32+sh) / d) + 1, sh = floor(log2 d); powers of two carry mul = 0 (plain shift).
+struct FastDiv { unsigned mul, sh; };
+inline FastDiv make_fastdiv(unsigned d) {
+    FastDiv f; unsigned s = 0; while ((2u << s) <= d) ++s;
+    f.sh = s;
+    f.mul = ((1u << s) == d) ? 0u : (unsigned)((((unsigned long long)1 << (32 + s)) / d) + 1);
+    return f;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned n, FastDiv f) { return f.mul ? (__umulhi(n, f.mul) >> f.sh) : (n >> f.sh); }
+
+// ----------------------------------------------------------------------------------------
+// operands
+// ----------------------------------------------------------------------------------------
+// dense P16 matrix: RR: rows = x (I or J), cols = r.   XX: rows = r, cols = x.
+struct PDense { const void* p; unsigned ld; int rows, cols; };
+// im2col view of an NHWC P16 tensor: rows = output pixels (N*OH*OW), cols = (tap, channel) = R*S*C
+struct PPatch { const void* p; int N, H, W, C, OH, OW, R, S, stride, pad; int rows, cols; FastDiv dOW, dOHW; };
+
+// ---- RR: the reduction index is the contiguous one; a lane loads 16 bytes = 8 r of one half of ONE row ----
+struct RRDense {
+    using Op = PDense;
+    using Col = int;                                          // (XX-mode state: unused)
+    struct Row { unsigned off; bool ok; };
+    struct Step {};                                           // per-K-step uniform state: none
+    static __device__ __forceinline__ Row row(const Op& op, int r, int lim) { Row c; c.ok = r < lim; c.off = (unsigned)r * op.ld * 4u; return c; }
+    static __device__ __forceinline__ Step step_init(const Op&, int) { return {}; }
+    static __device__ __forceinline__ void step_next(const Op&, Step&) {}
+    // q = 16-byte chunk inside the step's 128-byte row segment (q >> 1 = which 8 r, q & 1 = hi / lo)
+    static __device__ __forceinline__ unsigned voff(const Op& op, const Row& c, const Step&, int r0, int q, int r_lim) {
+        return (c.ok && r0 + 8 * (q >> 1) < r_lim) ? c.off + (unsigned)r0 * 4u + 16u * (unsigned)q : OOB;
+    }
+};
+struct RRPatch {
+    using Op = PPatch;
+    using Col = int;
+    struct Row { int nbase, ih0, iw0; bool ok; };
+    struct Step { int tr, ts, c0; };                          // tap (row, col) and first channel of the K-step (C % 32 == 0)
+    static __device__ __forceinline__ Row row(const Op& op, int r, int lim) {
+        Row c; c.ok = r < lim;
+        const int ohw = op.OH * op.OW;
+        const int n = r / ohw, rem = r - n * ohw, oh = rem / op.OW, ow = rem - oh * op.OW;
+        c.nbase = n * op.H * op.W; c.ih0 = oh * op.stride - op.pad; c.iw0 = ow * op.stride - op.pad;
+        return c;
+    }
+    static __device__ __forceinline__ Step step_init(const Op& op, int r0) {
+        Step s; const int tap = r0 / op.C; s.c0 = r0 - tap * op.C; s.tr = tap / op.S; s.ts = tap - s.tr * op.S; return s;
+    }
+    static __device__ __forceinline__ void step_next(const Op& op, Step& s) {
+        s.c0 += BK;
+        if (s.c0 >= op.C) { s.c0 = 0; if (++s.ts == op.S) { s.ts = 0; ++s.tr; } }
+    }
+    static __device__ __forceinline__ unsigned voff(const Op& op, const Row& c, const Step& s, int r0, int q, int r_lim) {
+        const int ih = c.ih0 + s.tr, iw = c.iw0 + s.ts;
+        const bool ok = c.ok && r0 + 8 * (q >> 1) < r_lim && (unsigned)ih < (unsigned)op.H && (unsigned)iw < (unsigned)op.W;
+        return ok ? ((unsigned)(c.nbase + ih * op.W + iw) * (unsigned)op.C + (unsigned)s.c0) * 4u + 16u * (unsigned)q : OOB;
+    }
+};
+
+// ---- XX: the reduction index is the strided one; a lane loads 16 bytes = 8 x-columns of one half of ONE r-row ----
+struct XXDense {
+    using Op = PDense;
+    using Row = int; using Step = int;                        // (RR-mode state: unused)
+    struct Col { unsigned off; bool ok; };                    // per lane: byte offset of its chunk inside a row
+    static __device__ __forceinline__ Col col(const Op& op, int x0, int slot, int x_lim) {
+        Col c; c.ok = x0 + 8 * (slot >> 1) < x_lim; c.off = (unsigned)x0 * 4u + 16u * (unsigned)slot; return c;
+    }
+    static __device__ __forceinline__ unsigned voff(const Op& op, const Col& c, int r, int r_lim) {
+        return (c.ok && r < r_lim) ? (unsigned)r * op.ld * 4u + c.off : OOB;
+    }
+};
+struct XXPatch {
+    using Op = PPatch;
+    using Row = int; using Step = int;
+    struct Col { int tr, ts; unsigned off; bool ok; };        // tap of the lane's 8 columns, channel byte offset inside the pixel
+    static __device__ __forceinline__ Col col(const Op& op, int x0, int slot, int x_lim) {
+        Col c; const int x = x0 + 8 * (slot >> 1);
+        c.ok = x < x_lim;
+        const int tap = x / op.C, ch = x - tap * op.C;
+        c.tr = tap / op.S; c.ts = tap - c.tr * op.S;
+        c.off = (unsigned)ch * 4u + 16u * (unsigned)(slot & 1);
+        return c;
+    }
+    static __device__ __forceinline__ unsigned voff(const Op& op, const Col& c, int r, int r_lim) {
+        const unsigned n = fdiv((unsigned)r, op.dOHW), rem = (unsigned)r - n * (unsigned)(op.OH * op.OW);
+        const unsigned oh = fdiv(rem, op.dOW), ow = rem - oh * (unsigned)op.OW;
+        const int ih = (int)oh * op.stride - op.pad + c.tr, iw = (int)ow * op.stride - op.pad + c.ts;
+        const bool ok = c.ok && r < r_lim && (unsigned)ih < (unsigned)op.H && (unsigned)iw < (unsigned)op.W;
+        return ok ? ((n * (unsigned)op.H + (unsigned)ih) * (unsigned)op.W + (unsigned)iw) * (unsigned)op.C * 4u + c.off : OOB;
+    }
+};
+
+// ----------------------------------------------------------------------------------------
+// LDS images (one stage = A tile then B tile; 128 bytes per x-row per K-step in both modes)
+//
+// RR: tile[x][8 slots of 16 B]; slot s of row x holds source chunk s ^ ((x >> 1) & 7) of the row's 128-byte
+//     K-step segment [hi0 lo0 hi1 lo1 hi2 lo2 hi3 lo3] - the XOR spreads the 16 rows of a ds_read_b128 lane
+//     group over all 16 slots of the 256-byte bank row (conflict-free).
+// XX: tile[r = 32 rows][BX/4 slots of 16 B]; slot s of row r holds source chunk s ^ swz(r),
+//     swz(r) = ((r & 1) << 3) | ((r >> 1) & 1): the four rows a ds_read_b64_tr_b16 half-wave touches land in
+//     four disjoint quarter bank rows (conflict-free).
+// Loads write LDS linearly (wave-uniform base + lane * 16), so the swizzle is applied to the SOURCE chunk a
+// lane fetches and, identically, to the slot a fragment read addresses.
+// ----------------------------------------------------------------------------------------
+__device__ __forceinline__ int xx_swz(int r) { return ((r & 1) << 3) | ((r >> 1) & 1); }
+
+template <int BM, int BN, int WM, int WN, class LA, class LB, bool XX, bool F16>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN <= 4 && BM * BN <= 128 * 128) ? 2 : 1)
+void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
+{
+    constexpr int NW = WM * WN, NT = NW * 64;
+    constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
+    static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 MFMA tile");
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int NIA = A_BYTES / 1024 / NW, NIB = B_BYTES / 1024 / NW;      // 1 KiB wave-instructions per wave per stage
+    static_assert(NIA >= 1 && NIB >= 1 && NIA * NW * 1024 == A_BYTES && NIB * NW * 1024 == B_BYTES, "tile / wave count mismatch");
+    constexpr int LDS_BYTES = (2 * STAGE_BYTES > BM * BN * 4) ? 2 * STAGE_BYTES : BM * BN * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int wg = xcd_tile(blockIdx.x, g.tiles_i * g.tiles_j);
+    const int tile_i = wg / g.tiles_j, tile_j = wg - tile_i * g.tiles_j;
+    const int i0 = tile_i * BM, j0 = tile_j * BN;
+
+    int r_begin = 0, r_end = g.R;
+    if (g.splitk > 1) { r_begin = blockIdx.z * g.r_chunk; r_end = min(g.R, r_begin + g.r_chunk); }
+
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(opa.p);
+    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(opb.p);
+
+    // ---------------- staging: HBM -> LDS, 16 bytes per lane, no registers ----------------
+    typename LA::Row rowA[NIA]; typename LB::Row rowB[NIB]; typename LA::Col colA[NIA]; typename LB::Col colB[NIB];
+    int qA[NIA], qB[NIB], rrA[NIA], rrB[NIB];          // RR: source chunk;  XX: row inside the stage
+    if constexpr (!XX) {
+#pragma unroll
+        for (int t = 0; t < NIA; ++t) {
+            const int x = (t * NW + wave) * 8 + (lane >> 3);
+            qA[t] = (lane & 7) ^ ((x >> 1) & 7);
+            rowA[t] = LA::row(opa, i0 + x, opa.rows);
+        }
+#pragma unroll
+        for (int t = 0; t < NIB; ++t) {
+            const int x = (t * NW + wave) * 8 + (lane >> 3);
+            qB[t] = (lane & 7) ^ ((x >> 1) & 7);
+            rowB[t] = LB::row(opb, j0 + x, opb.rows);
+        }
+    } else {
+        constexpr int SA = BM / 4, SB = BN / 4;           // 16-byte slots per row
+        static_assert(SA >= 16 && SB >= 16 && SA <= 64 && SB <= 64, "XX tiles: 64 <= BX <= 256");
+#pragma unroll
+        for (int t = 0; t < NIA; ++t) {
+            const int r = (t * NW + wave) * (64 / SA) + lane / SA;
+            rrA[t] = r;
+            colA[t] = LA::col(opa, i0, (lane % SA) ^ xx_swz(r), opa.cols);
+        }
+#pragma unroll
+        for (int t = 0; t < NIB; ++t) {
+            const int r = (t * NW + wave) * (64 / SB) + lane / SB;
+            rrB[t] = r;
+            colB[t] = LB::col(opb, j0, (lane % SB) ^ xx_swz(r), opb.cols);
+        }
+    }
+    // RR: per-K-step uniform state of the patch loaders (tap, first channel)
+    typename LA::Step stA; typename LB::Step stB;
+    if constexpr (!XX) { stA = LA::step_init(opa, r_begin); stB = LB::step_init(opb, r_begin); }
+
+    auto issue = [&](int buf, int r0) {
+        unsigned char* sa = lds + buf * STAGE_BYTES;
+        unsigned char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int t = 0; t < NIA; ++t) {
+            unsigned vo;
+            if constexpr (!XX) vo = LA::voff(opa, rowA[t], stA, r0, qA[t], min(r_end, opa.cols));
+            else               vo = LA::voff(opa, colA[t], r0 + rrA[t], min(r_end, opa.rows));
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(sa + (t * NW + wave) * 1024), 16, (int)vo, 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < NIB; ++t) {
+            unsigned vo;
+            if constexpr (!XX) vo = LB::voff(opb, rowB[t], stB, r0, qB[t], min(r_end, opb.cols));
+            else               vo = LB::voff(opb, colB[t], r0 + rrB[t], min(r_end, opb.rows));
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void*)(sb + (t * NW + wave) * 1024), 16, (int)vo, 0, 0, 0);
+        }
+        if constexpr (!XX) { LA::step_next(opa, stA); LB::step_next(opb, stB); }
+    };
+
+    // ---------------- accumulators ----------------
+    constexpr int TM2 = F16 ? TM : 1, TN2 = F16 ? TN : 1;
+    f32x16 acc[TM][TN], acc2[TM2][TN2];       // acc2: the 2^11-scaled cross products of the f16 pair
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+#pragma unroll
+    for (int a = 0; a < TM2; ++a)
+#pragma unroll
+        for (int b = 0; b < TN2; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc2[a][b][e] = 0.f;
+
+    // ---------------- fragment reads + MFMAs of one stage ----------------
+    auto frag_rr = [&](const unsigned char* tile, int x, int ks, u32x4& hi, u32x4& lo) {
+        // row x, k chunk kc = 2 * ks + lh: hi in slot (2 kc) ^ swz, lo in the neighbouring slot
+        const int s = (2 * (2 * ks + lh)) ^ ((x >> 1) & 7);
+        const unsigned char* p = tile + x * 128;
+        hi = *reinterpret_cast<const u32x4*>(p + s * 16);
+        lo = *reinterpret_cast<const u32x4*>(p + (s ^ 1) * 16);
+    };
+    auto frag_xx = [&](const unsigned char* tile, int rowbytes, int xw, int ks, u32x4& hi, u32x4& lo) {
+        // ds_read_b64_tr_b16: lanes 16g .. 16g+15 read a 4-row x 16-column block, lane 4q+p supplies row q,
+        // columns 4p .. 4p+3; lane i receives column i of the 4 rows.  Two reads (4 k each) per half.
+        const int g16 = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3;
+        const int unit = (xw + 16 * g16 + 4 * p) >> 3;                         // 8-column group
+        u32x2 h[2], l[2];
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+            const int r = ks * 16 + 8 * lh + 4 * t2 + q;
+            const int s = (2 * unit) ^ xx_swz(r);
+            const unsigned char* ptr = tile + r * rowbytes + s * 16 + 8 * (p & 1);
+            h[t2] = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)ptr));
+            l[t2] = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + r * rowbytes + (s ^ 1) * 16 + 8 * (p & 1))));
+        }
+        hi[0] = h[0][0]; hi[1] = h[0][1]; hi[2] = h[1][0]; hi[3] = h[1][1];
+        lo[0] = l[0][0]; lo[1] = l[0][1]; lo[2] = l[1][0]; lo[3] = l[1][1];
+    };
+    auto compute = [&](int buf) {
+        const unsigned char* tA = lds + buf * STAGE_BYTES;
+        const unsigned char* tB = tA + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            u32x4 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                if constexpr (!XX) frag_rr(tA, wm * WTM + a * 32 + li, ks, ah[a], al[a]);
+                else               frag_xx(tA, BM * 4, wm * WTM + a * 32, ks, ah[a], al[a]);
+            }
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                if constexpr (!XX) frag_rr(tB, wn * WTN + b * 32 + li, ks, bh[b], bl[b]);
+                else               frag_xx(tB, BN * 4, wn * WTN + b * 32, ks, bh[b], bl[b]);
+            }
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    if constexpr (F16) {
+#define H8(v) __builtin_bit_cast(f16x8, v)
+                        acc2[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(al[a]), H8(bh[b]), acc2[a][b], 0, 0, 0);
+                        acc2[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(ah[a]), H8(bl[b]), acc2[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(ah[a]), H8(bh[b]), acc[a][b], 0, 0, 0);
+#undef H8
+                    } else {
+#define BF8(v) __builtin_bit_cast(bf16x8, v)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF8(al[a]), BF8(bh[b]), acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF8(ah[a]), BF8(bl[b]), acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF8(ah[a]), BF8(bh[b]), acc[a][b], 0, 0, 0);
+#undef BF8
+                    }
+                }
+        }
+    };
+
+    // ---------------- main loop: one barrier per K-step, the next stage's loads fly under the MFMAs ----------------
+    const int nk = (r_end - r_begin + BK - 1) / BK;
+    if (nk > 0) issue(0, r_begin);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();          // vmcnt(0) + barrier: stage kt has landed for every wave, and every wave is done reading stage kt-1
+        if (kt + 1 < nk) issue((kt + 1) & 1, r_begin + (kt + 1) * BK);
+        compute(kt & 1);
+    }
+
+    // ---------------- epilogue ----------------
+    if constexpr (F16) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[a][b][e] += acc2[a][b][e] * (1.f / LO_SCALE);
+    }
+    gemm_epilogue<BM, BN, WM, WN, NT, LDS_BYTES / 4>(acc, g, reinterpret_cast<float*>(lds), tile_i, i0, j0, g.c);
+}
+
+// ----------------------------------------------------------------------------------------
+// host-side dispatch
+// ----------------------------------------------------------------------------------------
+enum { T_128x128 = 0, T_128x64 = 1, T_64x64 = 2 };
+
+// Bigger tiles stage fewer bytes per FLOP (128x128: 32 FLOP per staged byte, 64x64: 16) but need enough
+// workgroups to fill 256 CUs x 2 resident workgroups.
+int choose_tile(int64_t I, int64_t J, int64_t z) {
+    static int forced = -2;
+    if (forced == -2) {
+        forced = -1;
+        if (const char* e = getenv("BDETR_STILE")) forced = !strcmp(e, "128x128") ? T_128x128 : !strcmp(e, "128x64") ? T_128x64 : !strcmp(e, "64x64") ? T_64x64 : -1;
+    }
+    if (forced >= 0) return (forced != T_64x64 && J < 64) ? T_64x64 : forced;
+    const int64_t cus = num_cus();
+    auto tiles = [&](int bm, int bn) { return cdiv64(I, bm) * cdiv64(J, bn) * z; };
+    if (J % 128 == 0 && tiles(128, 128) >= cus) return T_128x128;
+    if (tiles(128, 64) >= cus) return T_128x64;
+    return T_64x64;
+}
+
+template <int BM, int BN, int WM, int WN, class LA, class LB, bool XX, bool F16>
+int launch_cfg(const typename LA::Op& a, const typename LB::Op& b, GemmParams g, int zdim, hipStream_t st, int kind) {
+    g.tiles_i = (int)cdiv64(g.I, BM);
+    g.tiles_j = (int)cdiv64(g.J, BN);
+    dim3 grid(g.tiles_i * g.tiles_j, 1, zdim);
+    g.vec_store = (g.J % 4 == 0) && (g.ldc % 4 == 0) && aligned16(g.c);
+    const bool prof = g_prof_on;
+    if (prof) prof_begin(st, 2.0 * (double)g.I * (double)g.J * (double)g.R, g.I, g.J, g.R, zdim, BM, BN,
+                         (F16 ? AR_P16_F16 : AR_P16_BF16) * 10000 + kind);
+    hipLaunchKernelGGL((sgemm_kernel<BM, BN, WM, WN, LA, LB, XX, F16>), grid, dim3(WM * WN * 64), 0, st, a, b, g);
+    if (prof) prof_end(st);
+    return bdetr_launch_status("sgemm");
+}
+
+template <class LA, class LB, bool XX, bool F16>
+int launch_any(const typename LA::Op& a, const typename LB::Op& b, const GemmParams& g, int zdim, hipStream_t st, int kind, int tile) {
+    if (tile == T_128x128) return launch_cfg<128, 128, 2, 2, LA, LB, XX, F16>(a, b, g, zdim, st, kind);
+    if (tile == T_128x64)  return launch_cfg<128, 64, 2, 2, LA, LB, XX, F16>(a, b, g, zdim, st, kind);
+    return launch_cfg<64, 64, 2, 2, LA, LB, XX, F16>(a, b, g, zdim, st, kind);
+}
+
+constexpr int64_t MAX_OPERAND_ELEMS = (int64_t)(NUM_RECORDS / 4) - 64;
+bool span_ok(int64_t elems) { return elems >= 0 && elems <= MAX_OPERAND_ELEMS; }
+
+int check_conv(const bdetr_conv_desc* d, const char* who) {
+    BDETR_CHECK_ARG(d != nullptr, "%s: null desc", who);
+    BDETR_CHECK_ARG(d->N > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->K > 0 && d->R > 0 && d->S > 0 && d->stride > 0 && d->pad >= 0,
+                    "%s: bad conv geometry", who);
+    BDETR_CHECK_ARG(d->OH == (d->H + 2 * d->pad - d->R) / d->stride + 1 && d->OW == (d->W + 2 * d->pad - d->S) / d->stride + 1,
+                    "%s: OH/OW inconsistent with geometry", who);
+    BDETR_CHECK_ARG(d->C % 8 == 0 && d->K % 8 == 0, "%s: the P16 layout needs channel counts that are multiples of 8 (C=%d K=%d)", who, d->C, d->K);
+    BDETR_CHECK_ARG((d->R == 1 && d->S == 1) || d->C % BK == 0, "%s: kernels larger than 1x1 need C %% %d == 0 (C=%d)", who, BK, d->C);
+    BDETR_CHECK_ARG((int64_t)d->N * d->OH * d->OW < (1LL << 31) && (int64_t)d->R * d->S * d->C < (1LL << 31) && (int64_t)d->N * d->H * d->W < (1LL << 31),
+                    "%s: problem too large", who);
+    BDETR_CHECK_ARG(span_ok((int64_t)d->N * d->H * d->W * d->C) && span_ok((int64_t)d->N * d->OH * d->OW * d->K) && span_ok((int64_t)d->K * d->R * d->S * d->C),
+                    "%s: a tensor spans 4 GB or more (the loaders use 32-bit buffer offsets); use a smaller per-GPU batch", who);
+    return 0;
+}
+
+PPatch make_patch(const void* p, int N, int H, int W, int C, int OH, int OW, int R, int S, int stride, int pad, int rows, int cols) {
+    PPatch o{p, N, H, W, C, OH, OW, R, S, stride, pad, rows, cols, make_fastdiv((unsigned)OW), make_fastdiv((unsigned)(OH * OW))};
+    return o;
+}
+bool is_1x1_dense(const bdetr_conv_desc* d) { return d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0; }
+
+}  // namespace
+
+// ----------------------------------------------------------------------------------------
+// C ABI
+// ----------------------------------------------------------------------------------------
+extern "C" int bdetr_p16_supported(const bdetr_conv_desc* d) {
+    if (!d || d->C % 8 || d->K % 8) return 0;
+    if (!(d->R == 1 && d->S == 1) && d->C % BK) return 0;
+    if (!(d->R == 1 && d->S == 1) && d->K % BK) return 0;          // backward-data gathers patches of dy: K plays C's role
+    if (d->stride > 1 && !(d->R == 1 && d->S == 1 && d->pad == 0)) return 0;
+    return 1;
+}
+
+static int fwd_tile(const bdetr_conv_desc* d) { return choose_tile((int64_t)d->N * d->OH * d->OW, d->K, 1); }
+
+extern "C" int bdetr_p16_conv2d_fwd_stat_chunks(const bdetr_conv_desc* d) {
+    if (check_conv(d, "bdetr_p16_conv2d_fwd_stat_chunks")) return -1;
+    const int t = fwd_tile(d);
+    return (int)cdiv64((int64_t)d->N * d->OH * d->OW, t == T_64x64 ? 64 : 128) * 2;      // tiles_i * WM
+}
+
+extern "C" int bdetr_p16_conv2d_fwd(const void* x_f16, const void* w_f16, const float* bias, float* y,
+                                    const bdetr_conv_desc* d, int act, float* stat_sum, float* stat_sq, void* stream) {
+    if (int e = check_conv(d, "bdetr_p16_conv2d_fwd")) return e;
+    BDETR_CHECK_ARG(x_f16 && w_f16 && y && aligned16(x_f16) && aligned16(w_f16), "bdetr_p16_conv2d_fwd: null / unaligned pointer");
+    BDETR_CHECK_ARG((stat_sum == nullptr) == (stat_sq == nullptr), "bdetr_p16_conv2d_fwd: stat_sum/stat_sq must both be set or both null");
+    const int M = d->N * d->OH * d->OW, Kd = d->R * d->S * d->C;
+    GemmParams g; init_params(g);
+    g.I = M; g.J = d->K; g.R = Kd;
+    g.c = y; g.ldc = d->K; g.bias = bias; g.act = act;
+    g.stat_sum = stat_sum; g.stat_sq = stat_sq;
+    PDense wop{w_f16, (unsigned)Kd, d->K, Kd};
+    hipStream_t st = (hipStream_t)stream;
+    const int tile = fwd_tile(d);
+    if (is_1x1_dense(d)) {
+        PDense xop{x_f16, (unsigned)d->C, M, d->C};
+        return launch_any<RRDense, RRDense, false, true>(xop, wop, g, 1, st, 0, tile);
+    }
+    PPatch xop = make_patch(x_f16, d->N, d->H, d->W, d->C, d->OH, d->OW, d->R, d->S, d->stride, d->pad, M, Kd);
+    return launch_any<RRPatch, RRDense, false, true>(xop, wop, g, 1, st, 1000, tile);
+}
+
+// dy_bf16: P16-bf16 [N,OH,OW,K]; wt_bf16: the transposed / tap-flipped P16-bf16 weight copy [C][R*S][K]
+// (bdetr_p16_pack_conv_weights); dx: fp32 [N,H,W,C]
+extern "C" int bdetr_p16_conv2d_bwd_data(const void* dy_bf16, const void* wt_bf16, float* dx,
+                                         const bdetr_conv_desc* d, int accumulate, void* stream) {
+    if (int e = check_conv(d, "bdetr_p16_conv2d_bwd_data")) return e;
+    BDETR_CHECK_ARG(dy_bf16 && wt_bf16 && dx, "bdetr_p16_conv2d_bwd_data: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int M = d->N * d->OH * d->OW;
+    GemmParams g; init_params(g);
+    g.c = dx; g.ldc = d->C; g.mode = accumulate ? ST_ACCUM : ST_STORE;
+    if (d->R == 1 && d->S == 1 && d->pad == 0) {
+        g.I = M; g.J = d->C; g.R = d->K;
+        if (d->stride > 1) {
+            if (!accumulate) {
+                hipError_t e = hipMemsetAsync(dx, 0, sizeof(float) * (size_t)d->N * d->H * d->W * d->C, st);
+                if (e != hipSuccess) { bdetr_set_error("bdetr_p16_conv2d_bwd_data: memset: %s", hipGetErrorString(e)); return (int)e; }
+            }
+            g.rowmap = 1; g.rm_OW = d->OW; g.rm_OHOW = d->OH * d->OW; g.rm_H = d->H; g.rm_W = d->W; g.rm_stride = d->stride;
+        }
+        PDense a{dy_bf16, (unsigned)d->K, M, d->K};
+        PDense b{wt_bf16, (unsigned)d->K, d->C, d->K};
+        return launch_any<RRDense, RRDense, false, false>(a, b, g, 1, st, 0, choose_tile(M, d->C, 1));
+    }
+    BDETR_CHECK_ARG(d->stride == 1 && d->R == d->S, "bdetr_p16_conv2d_bwd_data: stride>1 only for 1x1 convs; square kernels only");
+    BDETR_CHECK_ARG(d->K % BK == 0, "bdetr_p16_conv2d_bwd_data: K %% %d == 0 required for kernels larger than 1x1", BK);
+    // dx[n,ih,iw,c] = sum_{r',s',k} dy[n, ih - pad' + r', iw - pad' + s', k] * wt[c][r'][s'][k],  pad' = R-1-pad, wt pre-flipped
+    const int Mx = d->N * d->H * d->W, Kd = d->R * d->S * d->K;
+    g.I = Mx; g.J = d->C; g.R = Kd;
+    PPatch a = make_patch(dy_bf16, d->N, d->OH, d->OW, d->K, d->H, d->W, d->R, d->S, 1, d->R - 1 - d->pad, Mx, Kd);
+    PDense b{wt_bf16, (unsigned)Kd, d->C, Kd};
+    return launch_any<RRPatch, RRDense, false, false>(a, b, g, 1, st, 1000, choose_tile(Mx, d->C, 1));
+}
+
+static int wgrad_tile(const bdetr_conv_desc* d) {
+    const int64_t Kd = (int64_t)d->R * d->S * d->C;
+    return (d->K % 128 == 0 && Kd % 128 == 0) ? T_128x128 : T_64x64;
+}
+
+extern "C" int bdetr_p16_conv2d_bwd_weight_splitk(const bdetr_conv_desc* d) {
+    if (check_conv(d, "bdetr_p16_conv2d_bwd_weight_splitk")) return -1;
+    const int M = d->N * d->OH * d->OW;
+    const int64_t Kd = (int64_t)d->R * d->S * d->C;
+    const int bm = wgrad_tile(d) == T_128x128 ? 128 : 64;
+    const int64_t tiles = cdiv64(d->K, bm) * cdiv64(Kd, bm);
+    int64_t sk = cdiv64(3LL * num_cus(), tiles);
+    const int64_t maxsk = cdiv64(M, 8 * BK);       // keep >= 8 stages per split
+    if (sk > maxsk) sk = maxsk;
+    if (sk < 1) sk = 1;
+    if (sk > 512) sk = 512;
+    return (int)sk;
+}
+
+// x_bf16: P16-bf16 [N,H,W,C]; dy_bf16: P16-bf16 [N,OH,OW,K]; dw: fp32 [K][R][S][C], must hold zeros (or the
+// running sum) when splitk > 1 - the split-K slices add with float atomics
+extern "C" int bdetr_p16_conv2d_bwd_weight(const void* x_bf16, const void* dy_bf16, float* dw,
+                                           const bdetr_conv_desc* d, int splitk, void* stream) {
+    if (int e = check_conv(d, "bdetr_p16_conv2d_bwd_weight")) return e;
+    BDETR_CHECK_ARG(x_bf16 && dy_bf16 && dw, "bdetr_p16_conv2d_bwd_weight: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int M = d->N * d->OH * d->OW, Kd = d->R * d->S * d->C;
+    if (splitk <= 0) splitk = bdetr_p16_conv2d_bwd_weight_splitk(d);
+    GemmParams g; init_params(g);
+    g.I = d->K; g.J = Kd; g.R = M;
+    g.c = dw; g.ldc = Kd;
+    int zdim = 1;
+    if (splitk > 1) {
+        g.r_chunk = (int)(cdiv64(cdiv64(M, splitk), BK) * BK);
+        zdim = (int)cdiv64(M, g.r_chunk);
+        g.splitk = zdim > 1 ? zdim : 2;
+        g.mode = ST_ATOMIC;
+    }
+    PDense a{dy_bf16, (unsigned)d->K, M, d->K};          // rows = r (pixels), cols = i (output channels)
+    const int tile = wgrad_tile(d);
+    if (is_1x1_dense(d)) {
+        PDense b{x_bf16, (unsigned)d->C, M, d->C};
+        return launch_any<XXDense, XXDense, true, false>(a, b, g, zdim, st, 2000, tile);
+    }
+    PPatch b = make_patch(x_bf16, d->N, d->H, d->W, d->C, d->OH, d->OW, d->R, d->S, d->stride, d->pad, M, Kd);
+    return launch_any<XXDense, XXPatch, true, false>(a, b, g, zdim, st, 3000, tile);
+}

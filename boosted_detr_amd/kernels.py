@@ -216,6 +216,94 @@ def conv2d_bwd_weight(x, dy, g: ConvGeom, dw: Optional[torch.Tensor] = None, pre
 
 
 # --------------------------------------------------------------------------------------
+# pre-split (P16) operand path of the convolutions - csrc/sgemm.hip, csrc/p16.hip
+# --------------------------------------------------------------------------------------
+# A P16 tensor is carried as a float32 torch tensor of the logical shape (4 bytes per element, never read as
+# floats): f16 pairs for forward operands, bf16 pairs for gradient operands (include/bdetr.h).
+_OVERFLOW = [None]
+
+
+def overflow_flag() -> torch.Tensor:
+    """Device int32 the P16-f16 producers set when a value leaves the f16 pair's range (|x| >= 65504 / not finite)."""
+    if _OVERFLOW[0] is None:
+        _OVERFLOW[0] = torch.zeros(1, dtype=torch.int32, device="cuda")
+    return _OVERFLOW[0]
+
+
+def p16_supported(g: ConvGeom) -> bool:
+    d = g.desc()
+    return bool(_lib.lib().bdetr_p16_supported(C.byref(d)))
+
+
+def p16_pack(x, want_f16=True, want_bf16=True):
+    """fp32 tensor (last dim % 8 == 0) -> (P16-f16 or None, P16-bf16 or None)."""
+    _chk(x)
+    f = torch.empty_like(x) if want_f16 else None
+    b = torch.empty_like(x) if want_bf16 else None
+    check(_lib.lib().bdetr_p16_pack(_p(x), x.numel(), _p(f), _p(b), _p(overflow_flag()) if want_f16 else None, _stream()), "p16_pack")
+    return f, b
+
+
+def p16_unpack(p, is_f16: bool):
+    _chk(p)
+    out = torch.empty_like(p)
+    check(_lib.lib().bdetr_p16_unpack(_p(p), int(is_f16), p.numel(), _p(out), _stream()), "p16_unpack")
+    return out
+
+
+def p16_pack_conv_weights(w, want_fwd=True, want_bwd=True):
+    """w [K,R,S,C] fp32 -> (P16-f16 [K,R,S,C] forward copy, P16-bf16 [C,R,S,K] transposed tap-flipped copy)."""
+    _chk(w)
+    K_, R, S, Cc = w.shape
+    wf = torch.empty_like(w) if want_fwd else None
+    wt = torch.empty((Cc, R, S, K_), dtype=torch.float32, device=w.device) if want_bwd else None
+    check(_lib.lib().bdetr_p16_pack_conv_weights(_p(w), K_, R, S, Cc, _p(wf), _p(wt), _p(overflow_flag()) if want_fwd else None, _stream()),
+          "p16_pack_conv_weights")
+    return wf, wt
+
+
+def p16_conv2d_fwd(x_f16, w_f16, bias, g: ConvGeom, act: int = ACT_NONE, want_stats: bool = False):
+    _chk(x_f16, w_f16, bias)
+    L = _lib.lib()
+    d = g.desc()
+    y = empty(g.N, g.OH, g.OW, g.K, like=x_f16)
+    psum = psq = None
+    nparts = 0
+    if want_stats:
+        nparts = L.bdetr_p16_conv2d_fwd_stat_chunks(C.byref(d))
+        if nparts <= 0:
+            check(-1, "p16_conv2d_fwd_stat_chunks")
+        psum = empty(nparts, g.K, like=x_f16)
+        psq = empty(nparts, g.K, like=x_f16)
+    check(L.bdetr_p16_conv2d_fwd(_p(x_f16), _p(w_f16), _p(bias), _p(y), C.byref(d), act, _p(psum), _p(psq), _stream()), "p16_conv2d_fwd")
+    return y, (psum, psq, nparts)
+
+
+def p16_conv2d_bwd_data(dy_bf16, wt_bf16, g: ConvGeom, dx: Optional[torch.Tensor] = None, accumulate: bool = False):
+    _chk(dy_bf16, wt_bf16, dx)
+    d = g.desc()
+    if dx is None:
+        assert not accumulate
+        dx = empty(g.N, g.H, g.W, g.C, like=dy_bf16)
+    check(_lib.lib().bdetr_p16_conv2d_bwd_data(_p(dy_bf16), _p(wt_bf16), _p(dx), C.byref(d), int(accumulate), _stream()), "p16_conv2d_bwd_data")
+    return dx
+
+
+def p16_conv2d_bwd_weight(x_bf16, dy_bf16, g: ConvGeom, dw: Optional[torch.Tensor] = None, prezeroed: bool = False):
+    _chk(x_bf16, dy_bf16, dw)
+    L = _lib.lib()
+    d = g.desc()
+    if dw is None:
+        dw = empty(g.K, g.R, g.S, g.C, like=x_bf16)
+        prezeroed = False
+    sk = L.bdetr_p16_conv2d_bwd_weight_splitk(C.byref(d))
+    if sk > 1 and not prezeroed:
+        check(L.bdetr_zero(_p(dw), dw.numel(), _stream()), "zero")
+    check(L.bdetr_p16_conv2d_bwd_weight(_p(x_bf16), _p(dy_bf16), _p(dw), C.byref(d), sk, _stream()), "p16_conv2d_bwd_weight")
+    return dw
+
+
+# --------------------------------------------------------------------------------------
 # GEMM
 # --------------------------------------------------------------------------------------
 def gemm_raw(I, J, R, a, lda, a_rc, b, ldb, b_rc, c, ldc, *, nb0=1, nb1=1, sa=(0, 0), sb=(0, 0), sc=(0, 0),

@@ -126,6 +126,43 @@ int bdetr_conv2d_bwd_weight(const float* x, const float* dy, float* dw,
                             const bdetr_conv_desc* d, int splitk, void* stream);
 int bdetr_conv2d_bwd_weight_splitk(const bdetr_conv_desc* d);
 
+/* ------------------------------------------------------------------------
+ * Pre-split ("P16") operand path of the same convolutions - csrc/sgemm.hip.  Replaces the same reference
+ * call sites as bdetr_conv2d_* (Keras Conv2D + autodiff inside keras.applications ResNet-50,
+ * backbone.py:37-38,57); used by the training step under BDETR_GEMM_SPLIT for every layer whose channel
+ * counts allow it (bdetr_p16_supported).
+ *
+ * P16 layout of a row-major [rows][C] matrix, C % 8 == 0, 4 bytes per element like fp32: every group of 8
+ * consecutive elements occupies 32 bytes = [8 x hi (16 bit)][8 x lo (16 bit)].
+ *   f16 pair  (forward operands):  hi = f16(x),  lo = f16((x - hi) * 2^11);  |x| < 65504 or the value is lost
+ *   bf16 pair (gradient operands): hi = bf16(x), lo = bf16(x - hi);          fp32 range
+ * The producer of a tensor writes it (bdetr_bn_apply_p16 / bdetr_bn_bwd_p16 / bdetr_p16_pack*), the GEMM moves
+ * it HBM -> LDS with buffer_load ... lds and evaluates a product as three 16-bit MFMA products, fp32
+ * accumulate - the arithmetic of BDETR_GEMM_SPLIT without the in-kernel split.
+ *
+ * overflow_flag (device int*, may be null): set to 1 when a value cannot be represented by the f16 pair
+ * (|x| >= 65504 or not finite); never cleared by the library. */
+int bdetr_p16_supported(const bdetr_conv_desc* d);
+int bdetr_p16_pack(const float* x, int64_t n, void* f16_out, void* bf16_out, int* overflow_flag, void* stream);
+int bdetr_p16_unpack(const void* p, int is_f16, int64_t n, float* out, void* stream);
+/* w [K][R][S][C] fp32 -> w_f16 P16-f16 [K][R*S*C] (forward B operand) and wt_bf16 P16-bf16 [C][R*S][K] with
+ * flipped taps, wt[c][r][s][k] = w[k][R-1-r][S-1-s][c] (backward-data B operand); either may be null */
+int bdetr_p16_pack_conv_weights(const float* w, int K, int R, int S, int C, void* w_f16, void* wt_bf16,
+                                int* overflow_flag, void* stream);
+/* y fp32 [N,OH,OW,K] = conv(x_f16 P16-f16 [N,H,W,C], w_f16) + bias, act, BatchNorm partial column sums as
+ * bdetr_conv2d_fwd (stat_* sized with bdetr_p16_conv2d_fwd_stat_chunks rows) */
+int bdetr_p16_conv2d_fwd_stat_chunks(const bdetr_conv_desc* d);
+int bdetr_p16_conv2d_fwd(const void* x_f16, const void* w_f16, const float* bias, float* y,
+                         const bdetr_conv_desc* d, int act, float* stat_sum, float* stat_sq, void* stream);
+/* dx fp32 [N,H,W,C] (+)= conv_transpose(dy_bf16 P16-bf16 [N,OH,OW,K], wt_bf16) */
+int bdetr_p16_conv2d_bwd_data(const void* dy_bf16, const void* wt_bf16, float* dx,
+                              const bdetr_conv_desc* d, int accumulate, void* stream);
+/* dw fp32 [K][R][S][C] += sum over pixels of dy x patches(x); with splitk > 1 the slices add with float
+ * atomics, so dw must hold zeros (or the running sum) on entry */
+int bdetr_p16_conv2d_bwd_weight_splitk(const bdetr_conv_desc* d);
+int bdetr_p16_conv2d_bwd_weight(const void* x_bf16, const void* dy_bf16, float* dw,
+                                const bdetr_conv_desc* d, int splitk, void* stream);
+
 /* strided-batched GEMM - tf Dense / tf.linalg.matmul call sites
  * (transformers.py:41-48,62-65,86,97,101,174-177; prediction_heads.py:40-43,106-110,175-179)
  *   C[b][i][j] = act(alpha * sum_r A(b,i,r) * B(b,j,r) + bias[j])      (accumulate: C += ...)

@@ -1,0 +1,139 @@
+"""GPU parity of the pre-split ("P16") operand path (csrc/sgemm.hip, csrc/p16.hip) through the C ABI.
+
+* the packers against a bit-exact torch-CPU restatement of the layout (include/bdetr.h: groups of 8 elements =
+  [8 x hi][8 x lo]; f16 pair with the lo half scaled by 2^11, bf16 pair);
+* the three convolution products (forward on f16 pairs, backward-data / backward-weight on bf16 pairs) against fp64
+  F.conv2d and its autograd: tolerance 2e-5 x max|ref| forward (fp32-grade), 6e-5 gradients (2^-18 per product) -
+  the same bars as the in-kernel split arithmetic (tests/test_precision_gpu.py);
+* edge cases: ragged tiles in every dimension, padding borders, strided 1x1, C = 64 3x3 (two taps per 128 gathered
+  columns), images smaller than one K-step, split-K tails, the accumulate epilogue."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from test_kernels_gpu import close, dev, rnd
+
+pytestmark = pytest.mark.gpu
+
+
+def p16_ref(x: torch.Tensor, f16: bool) -> torch.Tensor:
+    """Bit-exact CPU restatement of the P16 layout; returned as int32 words (4 bytes per element)."""
+    x = x.float().contiguous()
+    if f16:
+        hi = x.half()
+        lo = ((x - hi.float()) * 2048.0).half()
+    else:
+        hi = x.bfloat16()
+        lo = (x - hi.float()).bfloat16()
+    g = x.shape[:-1] + (x.shape[-1] // 8, 8)
+    words = torch.stack([hi.view(torch.int16).reshape(g), lo.view(torch.int16).reshape(g)], dim=-2).contiguous()   # [..., C/8, 2, 8]
+    return words.view(torch.int32).reshape(x.shape)
+
+
+def bits(t: torch.Tensor) -> torch.Tensor:
+    return t.cpu().view(torch.int32)
+
+
+def test_pack_unpack_bit_exact(cuda):
+    from boosted_detr_amd import kernels as k
+    x = rnd(37, 11, 64, seed=1) * 3
+    x[0, 0, :8] = torch.tensor([0.0, -0.0, 1e-8, -3e-5, 65000.0, 1e-3, 255.5, -1.0])
+    f, b = k.p16_pack(dev(x))
+    assert torch.equal(bits(f), p16_ref(x, True))
+    assert torch.equal(bits(b), p16_ref(x, False))
+    # the f16 pair carries 22 significant bits, the bf16 pair 16
+    xf, xb = k.p16_unpack(f, True).cpu(), k.p16_unpack(b, False).cpu()
+    assert ((xf - x).abs() <= x.abs() * 2.0 ** -21 + 1e-10).all()
+    assert ((xb - x).abs() <= x.abs() * 2.0 ** -15 + 1e-30).all()
+    assert int(k.overflow_flag().item()) == 0
+    big = x.clone(); big[3, 3, 3] = 7e4
+    k.p16_pack(dev(big))
+    assert int(k.overflow_flag().item()) == 1          # beyond the f16 pair's range: flagged, never silent
+    k.overflow_flag().zero_()
+
+
+def test_weight_packs_bit_exact(cuda):
+    from boosted_detr_amd import kernels as k
+    for K_, R, C in ((64, 3, 64), (256, 1, 128), (32, 3, 32)):
+        w = rnd(K_, R, R, C, seed=K_) * 0.1
+        wf, wt = k.p16_pack_conv_weights(dev(w))
+        assert torch.equal(bits(wf), p16_ref(w, True))
+        want_t = w.flip(1, 2).permute(3, 1, 2, 0).contiguous()         # [C][R][S][K], taps flipped
+        assert torch.equal(bits(wt), p16_ref(want_t, False))
+
+
+# N, H, W, C, K, R, stride, pad
+P16_CONVS = [
+    (2, 20, 20, 64, 64, 3, 1, 1),        # C = 64: a 128-column weight-gradient tile spans two taps
+    (2, 20, 20, 64, 256, 1, 1, 0),
+    (2, 20, 20, 256, 128, 1, 2, 0),      # strided 1x1: patch loader forward, row-scatter backward-data
+    (1, 9, 11, 128, 32, 3, 1, 1),        # odd spatial sizes, K = 32 (ragged 64-wide tile)
+    (3, 7, 7, 512, 2048, 1, 1, 0),
+    (2, 14, 14, 256, 256, 3, 1, 1),
+    (5, 3, 3, 64, 96, 3, 1, 1),          # 9-pixel images: several images inside one 32-pixel K-step of the weight gradient
+    (1, 5, 6, 40, 72, 1, 1, 0),          # channel counts that are multiples of 8 only (1x1)
+    (4, 40, 40, 256, 256, 3, 1, 1),
+]
+# the benchmark's batch-16 layer shapes: every tile / loader combination the training step launches
+P16_BIG_CONVS = [
+    (8, 80, 80, 128, 128, 3, 1, 1), (16, 40, 40, 256, 256, 3, 1, 1), (16, 20, 20, 512, 512, 3, 1, 1),
+    (4, 160, 160, 64, 64, 3, 1, 1), (4, 80, 80, 256, 512, 1, 1, 0), (16, 80, 80, 512, 256, 1, 2, 0),
+    (16, 20, 20, 2048, 512, 1, 1, 0), (16, 20, 20, 512, 2048, 1, 1, 0), (4, 160, 160, 256, 64, 1, 1, 0),
+]
+
+
+def p16_conv_case(N, H, W, C, K, R, stride, pad, accumulate=True):
+    from boosted_detr_amd import kernels as k
+    x, w, b = rnd(N, H, W, C, seed=1), rnd(K, R, R, C, seed=2, scale=(R * R * C) ** -0.5), rnd(K, seed=3)
+    g = k.ConvGeom(N, H, W, C, K, R, R, stride, pad)
+    assert k.p16_supported(g)
+    xf, xb = k.p16_pack(dev(x))
+    wf, wt = k.p16_pack_conv_weights(dev(w))
+    y, (ps, pq, n) = k.p16_conv2d_fwd(xf, wf, dev(b), g, 0, want_stats=True)
+    xt = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    wtt = w.double().permute(0, 3, 1, 2).requires_grad_(True)
+    ref = F.conv2d(xt, wtt, b.double(), stride=stride, padding=pad)
+    r2 = ref.permute(0, 2, 3, 1).reshape(-1, K)
+    close(y, ref.permute(0, 2, 3, 1), rtol=2e-5)
+    close(ps.sum(0), r2.sum(0), rtol=1e-4)
+    close(pq.sum(0), (r2 * r2).sum(0), rtol=1e-4)
+    dy = rnd(*ref.shape, seed=4).double()
+    ref.backward(dy)
+    dyn = dy.permute(0, 2, 3, 1).float().contiguous()
+    _, dyb = k.p16_pack(dev(dyn), want_f16=False)
+    close(k.p16_conv2d_bwd_data(dyb, wt, g), xt.grad.permute(0, 2, 3, 1), rtol=6e-5)
+    if accumulate:
+        base = rnd(N, H, W, C, seed=9)
+        dx2 = dev(base)
+        k.p16_conv2d_bwd_data(dyb, wt, g, dx=dx2, accumulate=True)
+        close(dx2, base.double() + xt.grad.permute(0, 2, 3, 1), rtol=6e-5)
+    close(k.p16_conv2d_bwd_weight(xb, dyb, g), wtt.grad.permute(0, 2, 3, 1), rtol=6e-5)
+
+
+@pytest.mark.parametrize("N,H,W,C,K,R,stride,pad", P16_CONVS + P16_BIG_CONVS)
+def test_p16_conv_fwd_bwd(cuda, N, H, W, C, K, R, stride, pad):
+    p16_conv_case(N, H, W, C, K, R, stride, pad)
+
+
+@pytest.mark.parametrize("tile", ["128x128", "128x64", "64x64"])
+def test_p16_conv_every_tile(cuda, tile, monkeypatch):
+    """Each tile configuration on shapes with ragged edges in both tile dimensions (the chooser would not pick the
+    big tiles for problems this small): BDETR_STILE is read once per process, so this runs in a child process."""
+    import os
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from test_p16_gpu import p16_conv_case\n"
+            "for shp in [(2, 13, 9, 64, 224, 3, 1, 1), (3, 10, 10, 96, 136, 1, 1, 0), (2, 12, 12, 128, 72, 1, 2, 0)]:\n"
+            "    p16_conv_case(*shp)\n"
+            "print('TILE_OK')\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BDETR_STILE=tile), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "TILE_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def test_p16_unsupported_shapes_are_reported(cuda):
+    from boosted_detr_amd import kernels as k
+    assert not k.p16_supported(k.ConvGeom(2, 32, 32, 4, 64, 7, 7, 2, 3))          # the stem: 4 input channels
+    assert not k.p16_supported(k.ConvGeom(2, 8, 8, 40, 64, 3, 3, 1, 1))           # 3x3 needs C % 32 == 0
+    assert k.p16_supported(k.ConvGeom(2, 8, 8, 40, 64, 1, 1, 1, 0))
