@@ -33,7 +33,9 @@ PEAK_16BIT_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16/f16 MFM
 # A split product costs three 16-bit MFMA products, so the algorithmic-FLOP peak of the split arithmetics
 # is a third of the 16-bit MFMA peak.
 ARITH = {0: ("fp32 MFMA", PEAK_FP32_MFMA_TFLOPS), 1: ("split-bf16 (3 bf16 MFMA products)", PEAK_16BIT_MFMA_TFLOPS / 3),
-         2: ("split-fp16 (3 f16 MFMA products)", PEAK_16BIT_MFMA_TFLOPS / 3)}
+         2: ("split-fp16 (3 f16 MFMA products)", PEAK_16BIT_MFMA_TFLOPS / 3),
+         3: ("pre-split f16 pairs (3 f16 MFMA products, operands split by their producers)", PEAK_16BIT_MFMA_TFLOPS / 3),
+         4: ("pre-split bf16 pairs (3 bf16 MFMA products, operands split by their producers)", PEAK_16BIT_MFMA_TFLOPS / 3)}
 GFLOP_PER_IMAGE = 201.7                # 3 x fwd - conv1 bwd-data at 640^2, 6+6, N=100
 
 
@@ -286,7 +288,7 @@ def main():
             peak = fl.value / (peak_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": hbm_traffic_per_launch(),
-                    "kernel": "igemm_kernel (MFMA implicit-GEMM family: conv fwd/bwd-data/bwd-weight, dense; algorithmic FLOPs = 2*I*J*R)",
+                    "kernel": "igemm_kernel + sgemm_kernel (MFMA implicit-GEMM family: conv fwd/bwd-data/bwd-weight, dense; algorithmic FLOPs = 2*I*J*R)",
                     "peak_note": "FLOP-weighted harmonic mean of the per-arithmetic peaks in by_arithmetic (fp32 MFMA 157.3; split = 2500/3)",
                     "by_arithmetic": by_arith,
                     "launches_per_step": n.value // args.steps, "avg_launch_us": round(ms.value * 1e3 / n.value, 2),

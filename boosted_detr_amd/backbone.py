@@ -37,11 +37,12 @@ class _ConvBN(Layer):
         self.bn = ops.BNState(gamma, beta, mm, mv, RESNET_BN_EPS)
         self.built = True
 
-    def call(self, inputs, training=False, relu=True, residual=None, x_needs_grad=True):
+    def call(self, inputs, training=False, relu=True, residual=None, x_needs_grad=True, want_fp32=True, want_p16=False):
         x = inputs[0]
         # S18: BN uses batch statistics only when training AND the layer is trainable
         return ops.conv_bn(x, self.kernel, self.bias, self.bn, self.stride, self.pad, relu, residual=residual,
-                           training=training, bn_batch_stats=training and self.trainable, x_needs_grad=x_needs_grad)
+                           training=training, bn_batch_stats=training and self.trainable, x_needs_grad=x_needs_grad,
+                           want_fp32=want_fp32, want_p16=want_p16)
 
 
 class ResNet(Layer):
@@ -76,11 +77,15 @@ class ResNet(Layer):
         x = inputs[0]                                    # [B,H,W,4] prepared image
         x = self.stem([x], training=training, relu=True, x_needs_grad=False)
         x = ops.maxpool(x)
-        for blk in self.blocks:
+        # Inside a bottleneck the 1x1 -> 3x3 -> 1x1 links are consumed by convolutions only: on the pre-split operand
+        # path (ops.conv_bn, 'split' policy) they exist as 16-bit pairs and never as fp32 tensors; block outputs are
+        # also residuals / ReLU-mask sources and keep their fp32 tensor next to the pairs.
+        for i, blk in enumerate(self.blocks):
+            last = i + 1 == len(self.blocks)
             sc = blk["short"]([x], training=training, relu=False) if blk["short"] is not None else x
-            y = blk["c1"]([x], training=training, relu=True)
-            y = blk["c2"]([y], training=training, relu=True)
-            x = blk["c3"]([y], training=training, relu=True, residual=sc)     # BN -> Add([shortcut, x]) -> ReLU
+            y = blk["c1"]([x], training=training, relu=True, want_fp32=False, want_p16=True)
+            y = blk["c2"]([y], training=training, relu=True, want_fp32=False, want_p16=True)
+            x = blk["c3"]([y], training=training, relu=True, residual=sc, want_p16=not last)     # BN -> Add([shortcut, x]) -> ReLU
         return x
 
 

@@ -6,6 +6,7 @@
 // prediction_heads.py:42,108,177), keras LayerNormalization + Dropout + Add
 // (transformers.py:135-137,178-180), softmax (transformers.py:89, prediction_heads.py:111).
 #include "common.h"
+#include "p16.h"
 
 namespace {
 
@@ -201,6 +202,85 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             r = (g - db * inv_rows - xh * (dg * inv_rows)) * (rs * gm);
         }
         reinterpret_cast<f32x4*>(dx)[i] = r;
+    }
+}
+
+// ---- P16 producers (sgemm.hip operand layout): the same maps as bn_apply / bn_bwd_apply, 8 channels per thread,
+// writing the f16 pair (forward operand of the consumer conv), the bf16 pair (its weight-gradient operand) and / or
+// the fp32 tensor.  The fp32 arithmetic is identical to the kernels above (bn_affine), so a ReLU mask recomputed in
+// the backward pass agrees with what the forward wrote.
+__global__ __launch_bounds__(256) void bn_apply_p16_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ residual, int relu, float* __restrict__ out32,
+                                                           void* __restrict__ out_f16, void* __restrict__ out_bf16, int* __restrict__ overflow_flag,
+                                                           int64_t n8, int c8n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c8n) * 8;
+        float v[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const f32x4 xv = reinterpret_cast<const f32x4*>(x)[2 * i + h];
+            const f32x4 m = *reinterpret_cast<const f32x4*>(mean + c + 4 * h), rs = *reinterpret_cast<const f32x4*>(rstd + c + 4 * h);
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c + 4 * h), b = *reinterpret_cast<const f32x4*>(beta + c + 4 * h);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = bn_affine(xv[e], m[e], rs[e], g[e], b[e]);
+            if (residual != nullptr) o += reinterpret_cast<const f32x4*>(residual)[2 * i + h];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[4 * h + e] = relu ? fmaxf(o[e], 0.f) : o[e];
+            if (out32 != nullptr) reinterpret_cast<f32x4*>(out32)[2 * i + h] = f32x4{v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]};
+        }
+        if (out_f16 != nullptr) {
+            p16_store8<true>(reinterpret_cast<char*>(out_f16) + i * 32, v);
+            if (overflow_flag != nullptr && p16_f16_overflow(v)) *overflow_flag = 1;
+        }
+        if (out_bf16 != nullptr) p16_store8<false>(reinterpret_cast<char*>(out_bf16) + i * 32, v);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_p16_kernel(const float* __restrict__ dout, const float* __restrict__ out, const float* __restrict__ x,
+                                                               const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta,
+                                                               const float* __restrict__ dgamma, const float* __restrict__ dbeta, int relu, int frozen,
+                                                               float* __restrict__ dx32, void* __restrict__ dx_bf16, float* __restrict__ dres,
+                                                               int64_t n8, int c8n, float inv_rows) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % c8n) * 8;
+        float r8[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c = c0 + 4 * h;
+            f32x4 g = reinterpret_cast<const f32x4*>(dout)[2 * i + h];
+            const f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + c), gm = *reinterpret_cast<const f32x4*>(gamma + c);
+            const f32x4 m = *reinterpret_cast<const f32x4*>(mean + c);
+            f32x4 xv = {0.f, 0.f, 0.f, 0.f};
+            const bool recompute = relu && out == nullptr;
+            if (!frozen || recompute) xv = reinterpret_cast<const f32x4*>(x)[2 * i + h];
+            if (relu) {
+                if (!recompute) {
+                    const f32x4 o = reinterpret_cast<const f32x4*>(out)[2 * i + h];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (!(o[e] > 0.f)) g[e] = 0.f;
+                } else {
+                    const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (!(bn_affine(xv[e], m[e], rs[e], gm[e], bt[e]) > 0.f)) g[e] = 0.f;
+                }
+            }
+            if (dres != nullptr) reinterpret_cast<f32x4*>(dres)[2 * i + h] = g;
+            f32x4 r;
+            if (frozen) {
+                r = g * (rs * gm);
+            } else {
+                const f32x4 dg = *reinterpret_cast<const f32x4*>(dgamma + c), db = *reinterpret_cast<const f32x4*>(dbeta + c);
+                const f32x4 xh = (xv - m) * rs;
+                r = (g - db * inv_rows - xh * (dg * inv_rows)) * (rs * gm);
+            }
+            if (dx32 != nullptr) reinterpret_cast<f32x4*>(dx32)[2 * i + h] = r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r8[4 * h + e] = r[e];
+        }
+        p16_store8<false>(reinterpret_cast<char*>(dx_bf16) + i * 32, r8);
     }
 }
 
@@ -465,6 +545,38 @@ extern "C" int bdetr_bn_bwd(const float* dout, const float* out, const float* x,
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n4, 256, 2)), dim3(256), 0, st, dout, out, x, mean, rstd, gamma, beta, dgamma, dbeta,
                        relu, frozen, dx, dresidual, n4, C / 4, 1.0f / (float)rows);
     return bdetr_launch_status("bn_bwd");
+}
+
+extern "C" int bdetr_bn_apply_p16(const float* x, const float* mean, const float* rstd, const float* gamma,
+                                  const float* beta, const float* residual, int relu, float* out32, void* out_f16, void* out_bf16,
+                                  int* overflow_flag, int64_t rows, int C, void* stream) {
+    BDETR_CHECK_ARG(x && mean && rstd && gamma && beta && (out32 || out_f16 || out_bf16) && rows > 0 && C > 0 && C % 8 == 0,
+                    "bdetr_bn_apply_p16: bad arguments (C %% 8 == 0 required)");
+    const int64_t n8 = rows * C / 8;
+    hipLaunchKernelGGL(bn_apply_p16_kernel, dim3(ew_grid(n8, 256, 1)), dim3(256), 0, (hipStream_t)stream, x, mean, rstd, gamma, beta, residual, relu,
+                       out32, out_f16, out_bf16, overflow_flag, n8, C / 8);
+    return bdetr_launch_status("bn_apply_p16");
+}
+
+extern "C" int bdetr_bn_bwd_p16(const float* dout, const float* out, const float* x, const float* mean,
+                                const float* rstd, const float* gamma, const float* beta, int relu, int frozen,
+                                float* dx32, void* dx_bf16, float* dgamma, float* dbeta, float* dresidual,
+                                float* ws, int64_t rows, int C, void* stream) {
+    BDETR_CHECK_ARG(dout && x && mean && rstd && gamma && dx_bf16 && dgamma && dbeta && ws && rows > 0 && C > 0 && C % 8 == 0,
+                    "bdetr_bn_bwd_p16: bad arguments (C %% 8 == 0 required)");
+    BDETR_CHECK_ARG(!relu || out || beta, "bdetr_bn_bwd_p16: relu needs the forward output, or beta to recompute the mask from x");
+    hipStream_t st = (hipStream_t)stream;
+    ColGeom g = col_geom(C);
+    int64_t rpc = chunk_rows_for(rows, chunks_for_width(g.gx), 64);   // <= bdetr_bn_bwd_chunks(rows), which sizes ws
+    int nch = (int)cdiv64(rows, rpc);
+    float* pa = ws; float* pb = ws + (int64_t)nch * C;
+    BnBwdFn f{dout, out, x, mean, rstd, gamma, beta, C, relu};
+    hipLaunchKernelGGL((colreduce2_kernel<BnBwdFn>), dim3(g.gx, nch), dim3(256), 0, st, f, rows, C, g.tx, rpc, pa, pb);
+    hipLaunchKernelGGL(sum_partials2_kernel, dim3((C + 31) / 32), dim3(256), 0, st, pa, pb, nch, C, dbeta, dgamma);
+    const int64_t n8 = rows * C / 8;
+    hipLaunchKernelGGL(bn_bwd_apply_p16_kernel, dim3(ew_grid(n8, 256, 1)), dim3(256), 0, st, dout, out, x, mean, rstd, gamma, beta, dgamma, dbeta,
+                       relu, frozen, dx32, dx_bf16, dresidual, n8, C / 8, 1.0f / (float)rows);
+    return bdetr_launch_status("bn_bwd_p16");
 }
 
 extern "C" int bdetr_add_dropout_layernorm_fwd(const float* x, const float* y, const float* gamma, const float* beta,

@@ -43,16 +43,20 @@ __device__ __forceinline__ void p16_store8(void* group, const float (&v)[8]) {
 }
 template <bool F16>
 __device__ __forceinline__ void p16_load8(const void* group, float (&v)[8]) {
-    const p16_u32x4 hi = reinterpret_cast<const p16_u32x4*>(group)[0], lo = reinterpret_cast<const p16_u32x4*>(group)[1];
+    const p16_u32x4 hi4 = reinterpret_cast<const p16_u32x4*>(group)[0], lo4 = reinterpret_cast<const p16_u32x4*>(group)[1];
+    // scalars first: __builtin_bit_cast applied directly to a vector element (hi4[e]) was folded to element 0 by
+    // hipcc (ROCm 7.2) - every pair came out as pair 0
+    const unsigned hw[4] = {hi4[0], hi4[1], hi4[2], hi4[3]}, lw[4] = {lo4[0], lo4[1], lo4[2], lo4[3]};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
+        const unsigned h = hw[e], l = lw[e];
         if (F16) {
-            const p16_f32x2 h = __builtin_convertvector(__builtin_bit_cast(p16_f16x2, hi[e]), p16_f32x2);
-            const p16_f32x2 l = __builtin_convertvector(__builtin_bit_cast(p16_f16x2, lo[e]), p16_f32x2);
-            v[2 * e] = h[0] + l[0] * (1.f / P16_LO_SCALE); v[2 * e + 1] = h[1] + l[1] * (1.f / P16_LO_SCALE);
+            const p16_f32x2 hf = __builtin_convertvector(__builtin_bit_cast(p16_f16x2, h), p16_f32x2);
+            const p16_f32x2 lf = __builtin_convertvector(__builtin_bit_cast(p16_f16x2, l), p16_f32x2);
+            v[2 * e] = hf[0] + lf[0] * (1.f / P16_LO_SCALE); v[2 * e + 1] = hf[1] + lf[1] * (1.f / P16_LO_SCALE);
         } else {
-            v[2 * e] = __builtin_bit_cast(float, hi[e] << 16) + __builtin_bit_cast(float, lo[e] << 16);
-            v[2 * e + 1] = __builtin_bit_cast(float, hi[e] & 0xFFFF0000u) + __builtin_bit_cast(float, lo[e] & 0xFFFF0000u);
+            v[2 * e] = __builtin_bit_cast(float, h << 16) + __builtin_bit_cast(float, l << 16);
+            v[2 * e + 1] = __builtin_bit_cast(float, h & 0xFFFF0000u) + __builtin_bit_cast(float, l & 0xFFFF0000u);
         }
     }
 }

@@ -41,6 +41,15 @@ def to_device(a, dtype=torch.float32) -> torch.Tensor:
 # ----------------------------------------------------------------------------------------
 # variables
 # ----------------------------------------------------------------------------------------
+# Bumped whenever weight values change (optimizer step, assign): derived copies of a weight (the pre-split P16
+# operand copies of the conv kernels, ops.packed_weights) are valid for one version only.
+WEIGHTS_VERSION = [0]
+
+
+def bump_weights_version() -> None:
+    WEIGHTS_VERSION[0] += 1
+
+
 class Variable:
     """A model weight.  ``value`` is held in the kernels' layout (conv OHWI, dense [out][in]);
     ``numpy()`` / ``assign()`` speak the Keras layout (HWIO, [in][out])."""
@@ -81,6 +90,7 @@ class Variable:
 
     def assign(self, keras_array) -> None:
         t = to_device(self._to_internal(np.asarray(keras_array)))
+        bump_weights_version()
         if self.value is None:
             self.value = t
         else:

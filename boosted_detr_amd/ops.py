@@ -10,12 +10,13 @@ Tensors are NHWC / [B,T,D]; ops view them as 2-D row matrices internally.
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import torch
 
 from . import kernels as K
-from .engine import Variable, current_tape, on_side_stream
+from .engine import WEIGHTS_VERSION, Variable, current_tape, on_side_stream
 
 _dropout_site = [0]
 _dropout_base_seed = [0x5EED]
@@ -127,28 +128,125 @@ def _bn_backward(g2d, out2d, x2d, mean, rstd, bn: BNState, relu: bool, frozen: b
     return dx, dres
 
 
+# ---- pre-split (P16) operand path of the backbone convolutions (csrc/sgemm.hip) ----
+# Under the 'split' policy a training-mode Conv+BN unit whose channel counts allow it runs on operands that their
+# producers already wrote as 16-bit pairs: BatchNorm apply writes the f16 pair (forward operand of the next conv)
+# and the bf16 pair (its weight-gradient operand), BatchNorm backward writes the bf16 pair of dy, the weights are
+# packed once per optimizer step.  A tensor handle carries its packed companions as attributes:
+#   t._p16f / t._p16b   P16-f16 / P16-bf16 copies (fp32-shaped torch tensors, never read as floats)
+#   t._p16_only         the handle IS the f16 copy: no fp32 tensor was materialised (links inside a bottleneck)
+P16_ENABLED = [os.environ.get("BDETR_P16", "1") != "0"]
+
+
+def _p16_active() -> bool:
+    return P16_ENABLED[0] and K.get_gemm_precision() == "split"
+
+
+def as_fp32(t: torch.Tensor) -> torch.Tensor:
+    """The fp32 tensor behind a handle (unpacks a P16-only handle: 2^-23 relative round trip)."""
+    if getattr(t, "_p16_only", False):
+        return K.p16_unpack(t._p16f, True).view(t.shape)
+    return t
+
+
+def _packed_input(x: torch.Tensor, need_bf16: bool):
+    """(f16 pair, bf16 pair | None) of an activation, packing an fp32 handle once and caching the result on it."""
+    xf, xb = getattr(x, "_p16f", None), getattr(x, "_p16b", None)
+    if xf is None or (need_bf16 and xb is None):
+        f, b = K.p16_pack(x, want_f16=xf is None, want_bf16=need_bf16 and xb is None)
+        xf, xb = (f if xf is None else xf), (b if b is not None else xb)
+        x._p16f, x._p16b = xf, xb
+    return xf, xb
+
+
+def packed_weights(w: Variable, need_bwd: bool):
+    """(P16-f16 forward copy, P16-bf16 transposed tap-flipped copy | None) of a conv kernel, repacked when the
+    weights changed (optimizer step / assign)."""
+    c = getattr(w, "_p16", None)
+    if c is None or c[0] != WEIGHTS_VERSION[0]:
+        c = [WEIGHTS_VERSION[0], None, None]
+        w._p16 = c
+    if c[1] is None or (need_bwd and c[2] is None):
+        wf, wt = K.p16_pack_conv_weights(w.value, want_fwd=c[1] is None, want_bwd=need_bwd and c[2] is None)
+        c[1] = wf if c[1] is None else c[1]
+        c[2] = wt if wt is not None else c[2]
+    return c[1], c[2]
+
+
 def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int, pad: int, relu: bool,
             residual: Optional[torch.Tensor] = None, training: bool = False, bn_batch_stats: Optional[bool] = None,
-            x_needs_grad: bool = True) -> torch.Tensor:
-    """Conv2D(+bias) -> BatchNormalization -> [+ residual] -> [ReLU]  (keras ResNet-50 block unit)."""
+            x_needs_grad: bool = True, want_fp32: bool = True, want_p16: bool = False) -> torch.Tensor:
+    """Conv2D(+bias) -> BatchNormalization -> [+ residual] -> [ReLU]  (keras ResNet-50 block unit).
+
+    want_p16: the consumer is another conv_bn - also emit the packed copies of the output (P16 path only);
+    want_fp32=False: no fp32 output at all, the returned handle is the f16 copy (valid on the P16 path only,
+    otherwise ignored)."""
     N, H, W, Cin = x.shape
     Kout, R, S, _ = w.value.shape
     g = K.ConvGeom(N, H, W, Cin, Kout, R, S, stride, pad)
     use_batch = training if bn_batch_stats is None else bn_batch_stats
-    y, parts = K.conv2d_fwd(x, w.value, b.value, g, K.ACT_NONE, want_stats=use_batch)
-    y2d = _2d(y)
+    p16 = training and use_batch and _p16_active() and K.p16_supported(g)
     res2d = _2d(residual) if residual is not None else None
-    out2d, mean, rstd = _bn_forward(y2d, g.M, Kout, parts, bn, use_batch, True, res2d, relu)
-    out = out2d.view(N, g.OH, g.OW, Kout)
+    x_handle = x                 # the Tape keys gradients by the handle its producer returned
+    xb = None
+    if p16:
+        xf, xb = _packed_input(x, need_bf16=w.needs_grad)
+        wf, _ = packed_weights(w, need_bwd=False)
+        y, parts = K.p16_conv2d_fwd(xf, wf, b.value, g, K.ACT_NONE, want_stats=True)
+        y2d = _2d(y)
+        mean, rstd = K.bn_stats(g.M, Kout, parts, bn.eps, bn.momentum, True, bn.moving_mean.value, bn.moving_var.value, like=y2d)
+        fp32_out = want_fp32 or not want_p16
+        o32, of, ob = K.bn_apply_p16(y2d, mean, rstd, bn.gamma.value, bn.beta.value, res2d, relu,
+                                     want_fp32=fp32_out, want_f16=want_p16, want_bf16=want_p16)
+        out2d = o32
+        out = (o32 if fp32_out else of).view(N, g.OH, g.OW, Kout)
+        if want_p16:
+            out._p16f, out._p16b, out._p16_only = of.view(out.shape), ob.view(out.shape), not fp32_out
+    else:
+        x = as_fp32(x)
+        y, parts = K.conv2d_fwd(x, w.value, b.value, g, K.ACT_NONE, want_stats=use_batch)
+        y2d = _2d(y)
+        out2d, mean, rstd = _bn_forward(y2d, g.M, Kout, parts, bn, use_batch, True, res2d, relu)
+        out = out2d.view(N, g.OH, g.OW, Kout)
 
     def backward(g_out, acc=None):
-        dy, dres = _bn_backward(_2d(g_out.contiguous()), out2d, y2d, mean, rstd, bn, relu, not use_batch, residual is not None)
+        g2d = _2d(g_out.contiguous())
+        want_res = residual is not None
+        if p16 and _p16_active():
+            sg, sb = GradSink(bn.gamma), GradSink(bn.beta)
+            dyb, _, _, _, dres = K.bn_bwd_p16(g2d, out2d if (relu and want_res) else None, y2d, mean, rstd, bn.gamma.value, relu, False,
+                                              want_residual_grad=want_res, dgamma=sg.buf, dbeta=sb.buf, beta=bn.beta.value)
+            sg.commit()
+            sb.commit()
+            dyb4 = dyb.view(N, g.OH, g.OW, Kout)
+            if w.needs_grad or b.needs_grad:
+                with on_side_stream(xb, dyb):
+                    if w.needs_grad:
+                        s = GradSink(w)
+                        K.p16_conv2d_bwd_weight(xb, dyb4, g, dw=s.buf, prezeroed=s.mode == "direct")
+                        s.commit()
+                    if b.needs_grad:
+                        s = GradSink(b)             # a bias in front of a batch-statistics BN has an exactly zero gradient (see below)
+                        if s.mode != "direct":
+                            K.zero_(s.buf)
+                        s.commit()
+            dx = None
+            if x_needs_grad:
+                _, wt = packed_weights(w, need_bwd=True)
+                if acc is not None and acc[0] is not None:
+                    K.p16_conv2d_bwd_data(dyb4, wt, g, dx=acc[0].view(N, H, W, Cin), accumulate=True)
+                    dx = acc[0]
+                else:
+                    dx = _own(K.p16_conv2d_bwd_data(dyb4, wt, g))
+            return dx, (_own(dres.view(residual.shape)) if want_res else None)
+        x32 = as_fp32(x)
+        dy, dres = _bn_backward(g2d, out2d, y2d, mean, rstd, bn, relu, not use_batch, want_res)
         dy4 = dy.view(N, g.OH, g.OW, Kout)
         if w.needs_grad or b.needs_grad:
-            with on_side_stream(x, dy):
+            with on_side_stream(x32, dy):
                 if w.needs_grad:
                     s = GradSink(w)
-                    K.conv2d_bwd_weight(x, dy4, g, dw=s.buf, prezeroed=s.mode == "direct")
+                    K.conv2d_bwd_weight(x32, dy4, g, dw=s.buf, prezeroed=s.mode == "direct")
                     s.commit()
                 if b.needs_grad:
                     s = GradSink(b)
@@ -168,11 +266,11 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
                 dx = acc[0]
             else:
                 dx = _own(K.conv2d_bwd_data(dy4, w.value, g))
-        dr = _own(dres.view(residual.shape)) if residual is not None else None
+        dr = _own(dres.view(residual.shape)) if want_res else None
         return dx, dr
 
     backward.wants_acc = True
-    _rec([out], [x, residual], backward)
+    _rec([out], [x_handle, residual], backward)
     return out
 
 

@@ -21,7 +21,7 @@ import torch
 from . import _lib
 from . import kernels as K
 from . import ops
-from .engine import Layer, Tape, Variable, device, join_side_stream, recording, to_device
+from .engine import Layer, Tape, Variable, bump_weights_version, device, join_side_stream, recording, to_device
 
 
 # ----------------------------------------------------------------------------------------
@@ -129,6 +129,7 @@ class SGD:
             self.d_ptrs.data_ptr(), self.d_sizes.data_ptr(), len(self.vars), self.d_slab_tensor.data_ptr(),
             self.d_slab_first.data_ptr(), self.nslabs, self.d_partial.data_ptr(), self.d_norms.data_ptr(),
             self.d_lr.data_ptr(), self.momentum, self.clipnorm, float(grad_scale), st), "sgd")
+        bump_weights_version()
         self.iterations += 1
 
 

@@ -142,6 +142,17 @@ int bdetr_conv2d_bwd_weight_splitk(const bdetr_conv_desc* d);
  *
  * overflow_flag (device int*, may be null): set to 1 when a value cannot be represented by the f16 pair
  * (|x| >= 65504 or not finite); never cleared by the library. */
+/* BatchNormalization apply / backward of bdetr_bn_apply / bdetr_bn_bwd (same reference call sites, same fp32
+ * arithmetic) with P16 outputs for the consumer convolutions: out_f16 = forward operand, out_bf16 = weight-
+ * gradient operand, out32 = the fp32 tensor (residual / mask source); any of the three may be null.
+ * bdetr_bn_bwd_p16 writes the input gradient as a bf16 pair (dx_bf16) and, when dx32 != null, in fp32 too. */
+int bdetr_bn_apply_p16(const float* x, const float* mean, const float* rstd, const float* gamma,
+                       const float* beta, const float* residual, int relu, float* out32, void* out_f16,
+                       void* out_bf16, int* overflow_flag, int64_t rows, int C, void* stream);
+int bdetr_bn_bwd_p16(const float* dout, const float* out, const float* x, const float* mean,
+                     const float* rstd, const float* gamma, const float* beta, int relu, int frozen,
+                     float* dx32, void* dx_bf16, float* dgamma, float* dbeta, float* dresidual,
+                     float* ws, int64_t rows, int C, void* stream);
 int bdetr_p16_supported(const bdetr_conv_desc* d);
 int bdetr_p16_pack(const float* x, int64_t n, void* f16_out, void* bf16_out, int* overflow_flag, void* stream);
 int bdetr_p16_unpack(const void* p, int is_f16, int64_t n, float* out, void* stream);

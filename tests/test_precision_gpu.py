@@ -123,6 +123,9 @@ def test_bench_step_variants_are_all_oracle_tested(cuda, tmp_path):
             for shp in CONVS + BIG_CONVS:
                 conv_case("split", *shp)
             _grouped_case("split")
+            from test_p16_gpu import P16_BIG_CONVS, P16_CONVS, p16_conv_case
+            for shp in P16_CONVS + P16_BIG_CONVS:              # the pre-split operand kernels (csrc/sgemm.hip)
+                p16_conv_case(*shp, accumulate=True)
             tested = _prof_tuples(str(tmp_path / "tested.csv"))
         args = type("A", (), dict(model="detr", fashionpedia=False, backbone="ResNet", image=640, image_w=0, layers=6, queries=100,
                                   learners=3, batch=16))()

@@ -87,7 +87,8 @@ def test_gpu_cost_matrix_and_lsa_match_published_vectors(cuda):
     ct, cp = O.coco_to_tf(torch.tensor(bt[0, :2], dtype=torch.float64)), O.coco_to_tf(torch.tensor(bp[0, :2], dtype=torch.float64))
     l2 = ((10 * ct - 10 * cp) ** 2).mean(-1).numpy()
     giou_loss = (b_comp - 5 * l2) / 2
-    assert np.abs(giou_loss - np.array(g["giou_loss"])).max() <= 1e-4, giou_loss  # TFA giou_loss docstring pair (l2 term ~250: fp32 cancellation)
+    # the fp32 cost carries the 5 * l2 term (up to ~2e4 for the far-apart pair): allow its fp32 round-off
+    assert (np.abs(giou_loss - np.array(g["giou_loss"])) <= 2e-7 * np.abs(b_comp) + 1e-6).all(), giou_loss   # TFA giou_loss docstring pair
     # scipy docstring assignment through the on-GPU solver
     s = KATS["scipy_linear_sum_assignment"]
     match = kk.lsa(dev(np.array(s["cost"], np.float32)[None]), dev(np.array([3], np.int32), torch.int32)).cpu().numpy()[0]
