@@ -78,14 +78,15 @@ class ResNet(Layer):
         x = self.stem([x], training=training, relu=True, x_needs_grad=False)
         x = ops.maxpool(x)
         # Inside a bottleneck the 1x1 -> 3x3 -> 1x1 links are consumed by convolutions only: on the pre-split operand
-        # path (ops.conv_bn, 'split' policy) they exist as 16-bit pairs and never as fp32 tensors; block outputs are
-        # also residuals / ReLU-mask sources and keep their fp32 tensor next to the pairs.
+        # path (ops.conv_bn, 'split' policy) they exist as 16-bit pairs and never as fp32 tensors.  Block outputs are also
+        # the next block's shortcut (read back from the f16 pair) and their own ReLU-mask source in the backward pass (the
+        # hi halves of the bf16 pair); only the last one, which leaves the backbone, is written in fp32.
         for i, blk in enumerate(self.blocks):
             last = i + 1 == len(self.blocks)
             sc = blk["short"]([x], training=training, relu=False) if blk["short"] is not None else x
             y = blk["c1"]([x], training=training, relu=True, want_fp32=False, want_p16=True)
             y = blk["c2"]([y], training=training, relu=True, want_fp32=False, want_p16=True)
-            x = blk["c3"]([y], training=training, relu=True, residual=sc, want_p16=not last)     # BN -> Add([shortcut, x]) -> ReLU
+            x = blk["c3"]([y], training=training, relu=True, residual=sc, want_fp32=last, want_p16=not last)     # BN -> Add([shortcut, x]) -> ReLU
         return x
 
 

@@ -127,13 +127,18 @@ __device__ __forceinline__ float bn_affine(float v, float m, float rs, float g, 
 struct BnBwdFn {   // a = g (masked dout), b = g * xhat
     const float* dout; const float* out; const float* x; const float* mean; const float* rstd; const float* gamma; const float* beta;
     int C; int relu;
+    int out_p16 = 0;      // `out` is the bf16 pair copy of the forward output (P16 layout), not the fp32 tensor
     __device__ __forceinline__ void operator()(int64_t r, int c, f32x4& a, f32x4& b) const {
         f32x4 g = *reinterpret_cast<const f32x4*>(dout + r * C + c);
         f32x4 xv = *reinterpret_cast<const f32x4*>(x + r * C + c);
         f32x4 m = *reinterpret_cast<const f32x4*>(mean + c);
         f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + c);
         if (relu) {
-            if (out != nullptr) {
+            if (out != nullptr && out_p16) {
+                const unsigned pm = p16_positive4_bf16(out, (r * C + c) >> 2);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (!((pm >> e) & 1u)) g[e] = 0.f;
+            } else if (out != nullptr) {
                 f32x4 o = *reinterpret_cast<const f32x4*>(out + r * C + c);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) if (!(o[e] > 0.f)) g[e] = 0.f;
@@ -211,76 +216,84 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 // the backward pass agrees with what the forward wrote.
 __global__ __launch_bounds__(256) void bn_apply_p16_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           const float* __restrict__ residual, int relu, float* __restrict__ out32,
+                                                           const void* __restrict__ residual, int residual_p16, int relu, float* __restrict__ out32,
                                                            void* __restrict__ out_f16, void* __restrict__ out_bf16, int* __restrict__ overflow_flag,
-                                                           int64_t n8, int c8n) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % c8n) * 8;
-        float v[8];
+                                                           int64_t n4, int c4n) {
+    // n4 is even and the stride is even: the two lanes of a pair (one 8-element group) always run together
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4n) * 4;
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        const f32x4 m = *reinterpret_cast<const f32x4*>(mean + c), rs = *reinterpret_cast<const f32x4*>(rstd + c);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c), b = *reinterpret_cast<const f32x4*>(beta + c);
+        f32x4 o;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const f32x4 xv = reinterpret_cast<const f32x4*>(x)[2 * i + h];
-            const f32x4 m = *reinterpret_cast<const f32x4*>(mean + c + 4 * h), rs = *reinterpret_cast<const f32x4*>(rstd + c + 4 * h);
-            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c + 4 * h), b = *reinterpret_cast<const f32x4*>(beta + c + 4 * h);
-            f32x4 o;
+        for (int e = 0; e < 4; ++e) o[e] = bn_affine(v[e], m[e], rs[e], g[e], b[e]);
+        if (residual != nullptr) {
+            if (residual_p16) {
+                float r4[4];
+                p16_load4_f16(residual, i, r4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = bn_affine(xv[e], m[e], rs[e], g[e], b[e]);
-            if (residual != nullptr) o += reinterpret_cast<const f32x4*>(residual)[2 * i + h];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[4 * h + e] = relu ? fmaxf(o[e], 0.f) : o[e];
-            if (out32 != nullptr) reinterpret_cast<f32x4*>(out32)[2 * i + h] = f32x4{v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]};
+                for (int e = 0; e < 4; ++e) o[e] += r4[e];
+            } else {
+                o += reinterpret_cast<const f32x4*>(residual)[i];
+            }
         }
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+        }
+        if (out32 != nullptr) reinterpret_cast<f32x4*>(out32)[i] = o;
         if (out_f16 != nullptr) {
-            p16_store8<true>(reinterpret_cast<char*>(out_f16) + i * 32, v);
-            if (overflow_flag != nullptr && p16_f16_overflow(v)) *overflow_flag = 1;
+            p16_store4<true>(out_f16, i, o[0], o[1], o[2], o[3]);
+            if (overflow_flag != nullptr) {
+                const float mx = fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3])));
+                if (!(mx < P16_F16_LIMIT) || o[0] != o[0] || o[1] != o[1] || o[2] != o[2] || o[3] != o[3]) *overflow_flag = 1;
+            }
         }
-        if (out_bf16 != nullptr) p16_store8<false>(reinterpret_cast<char*>(out_bf16) + i * 32, v);
+        if (out_bf16 != nullptr) p16_store4<false>(out_bf16, i, o[0], o[1], o[2], o[3]);
     }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_apply_p16_kernel(const float* __restrict__ dout, const float* __restrict__ out, const float* __restrict__ x,
+__global__ __launch_bounds__(256) void bn_bwd_apply_p16_kernel(const float* __restrict__ dout, const void* __restrict__ out, int out_p16, const float* __restrict__ x,
                                                                const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta,
                                                                const float* __restrict__ dgamma, const float* __restrict__ dbeta, int relu, int frozen,
                                                                float* __restrict__ dx32, void* __restrict__ dx_bf16, float* __restrict__ dres,
-                                                               int64_t n8, int c8n, float inv_rows) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
-        const int c0 = (int)(i % c8n) * 8;
-        float r8[8];
+                                                               int64_t n4, int c4n, float inv_rows) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4n) * 4;
+        f32x4 g = reinterpret_cast<const f32x4*>(dout)[i];
+        const f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + c), gm = *reinterpret_cast<const f32x4*>(gamma + c);
+        const f32x4 m = *reinterpret_cast<const f32x4*>(mean + c);
+        f32x4 xv = {0.f, 0.f, 0.f, 0.f};
+        const bool recompute = relu && out == nullptr;
+        if (!frozen || recompute) xv = reinterpret_cast<const f32x4*>(x)[i];
+        if (relu) {
+            if (!recompute && out_p16) {
+                const unsigned pm = p16_positive4_bf16(out, i);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int c = c0 + 4 * h;
-            f32x4 g = reinterpret_cast<const f32x4*>(dout)[2 * i + h];
-            const f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + c), gm = *reinterpret_cast<const f32x4*>(gamma + c);
-            const f32x4 m = *reinterpret_cast<const f32x4*>(mean + c);
-            f32x4 xv = {0.f, 0.f, 0.f, 0.f};
-            const bool recompute = relu && out == nullptr;
-            if (!frozen || recompute) xv = reinterpret_cast<const f32x4*>(x)[2 * i + h];
-            if (relu) {
-                if (!recompute) {
-                    const f32x4 o = reinterpret_cast<const f32x4*>(out)[2 * i + h];
+                for (int e = 0; e < 4; ++e) if (!((pm >> e) & 1u)) g[e] = 0.f;
+            } else if (!recompute) {
+                const f32x4 o = reinterpret_cast<const f32x4*>(out)[i];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) if (!(o[e] > 0.f)) g[e] = 0.f;
-                } else {
-                    const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + c);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) if (!(bn_affine(xv[e], m[e], rs[e], gm[e], bt[e]) > 0.f)) g[e] = 0.f;
-                }
-            }
-            if (dres != nullptr) reinterpret_cast<f32x4*>(dres)[2 * i + h] = g;
-            f32x4 r;
-            if (frozen) {
-                r = g * (rs * gm);
+                for (int e = 0; e < 4; ++e) if (!(o[e] > 0.f)) g[e] = 0.f;
             } else {
-                const f32x4 dg = *reinterpret_cast<const f32x4*>(dgamma + c), db = *reinterpret_cast<const f32x4*>(dbeta + c);
-                const f32x4 xh = (xv - m) * rs;
-                r = (g - db * inv_rows - xh * (dg * inv_rows)) * (rs * gm);
-            }
-            if (dx32 != nullptr) reinterpret_cast<f32x4*>(dx32)[2 * i + h] = r;
+                const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + c);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) r8[4 * h + e] = r[e];
+                for (int e = 0; e < 4; ++e) if (!(bn_affine(xv[e], m[e], rs[e], gm[e], bt[e]) > 0.f)) g[e] = 0.f;
+            }
         }
-        p16_store8<false>(reinterpret_cast<char*>(dx_bf16) + i * 32, r8);
+        if (dres != nullptr) reinterpret_cast<f32x4*>(dres)[i] = g;
+        f32x4 r;
+        if (frozen) {
+            r = g * (rs * gm);
+        } else {
+            const f32x4 dg = *reinterpret_cast<const f32x4*>(dgamma + c), db = *reinterpret_cast<const f32x4*>(dbeta + c);
+            const f32x4 xh = (xv - m) * rs;
+            r = (g - db * inv_rows - xh * (dg * inv_rows)) * (rs * gm);
+        }
+        if (dx32 != nullptr) reinterpret_cast<f32x4*>(dx32)[i] = r;
+        p16_store4<false>(dx_bf16, i, r[0], r[1], r[2], r[3]);
     }
 }
 
@@ -548,17 +561,17 @@ extern "C" int bdetr_bn_bwd(const float* dout, const float* out, const float* x,
 }
 
 extern "C" int bdetr_bn_apply_p16(const float* x, const float* mean, const float* rstd, const float* gamma,
-                                  const float* beta, const float* residual, int relu, float* out32, void* out_f16, void* out_bf16,
+                                  const float* beta, const void* residual, int residual_p16, int relu, float* out32, void* out_f16, void* out_bf16,
                                   int* overflow_flag, int64_t rows, int C, void* stream) {
     BDETR_CHECK_ARG(x && mean && rstd && gamma && beta && (out32 || out_f16 || out_bf16) && rows > 0 && C > 0 && C % 8 == 0,
                     "bdetr_bn_apply_p16: bad arguments (C %% 8 == 0 required)");
-    const int64_t n8 = rows * C / 8;
-    hipLaunchKernelGGL(bn_apply_p16_kernel, dim3(ew_grid(n8, 256, 1)), dim3(256), 0, (hipStream_t)stream, x, mean, rstd, gamma, beta, residual, relu,
-                       out32, out_f16, out_bf16, overflow_flag, n8, C / 8);
+    const int64_t n4 = rows * C / 4;
+    hipLaunchKernelGGL(bn_apply_p16_kernel, dim3(ew_grid(n4, 256, 2)), dim3(256), 0, (hipStream_t)stream, x, mean, rstd, gamma, beta, residual, residual_p16, relu,
+                       out32, out_f16, out_bf16, overflow_flag, n4, C / 4);
     return bdetr_launch_status("bn_apply_p16");
 }
 
-extern "C" int bdetr_bn_bwd_p16(const float* dout, const float* out, const float* x, const float* mean,
+extern "C" int bdetr_bn_bwd_p16(const float* dout, const void* out, int out_p16, const float* x, const float* mean,
                                 const float* rstd, const float* gamma, const float* beta, int relu, int frozen,
                                 float* dx32, void* dx_bf16, float* dgamma, float* dbeta, float* dresidual,
                                 float* ws, int64_t rows, int C, void* stream) {
@@ -570,12 +583,12 @@ extern "C" int bdetr_bn_bwd_p16(const float* dout, const float* out, const float
     int64_t rpc = chunk_rows_for(rows, chunks_for_width(g.gx), 64);   // <= bdetr_bn_bwd_chunks(rows), which sizes ws
     int nch = (int)cdiv64(rows, rpc);
     float* pa = ws; float* pb = ws + (int64_t)nch * C;
-    BnBwdFn f{dout, out, x, mean, rstd, gamma, beta, C, relu};
+    BnBwdFn f{dout, reinterpret_cast<const float*>(out), x, mean, rstd, gamma, beta, C, relu, out_p16};
     hipLaunchKernelGGL((colreduce2_kernel<BnBwdFn>), dim3(g.gx, nch), dim3(256), 0, st, f, rows, C, g.tx, rpc, pa, pb);
     hipLaunchKernelGGL(sum_partials2_kernel, dim3((C + 31) / 32), dim3(256), 0, st, pa, pb, nch, C, dbeta, dgamma);
-    const int64_t n8 = rows * C / 8;
-    hipLaunchKernelGGL(bn_bwd_apply_p16_kernel, dim3(ew_grid(n8, 256, 1)), dim3(256), 0, st, dout, out, x, mean, rstd, gamma, beta, dgamma, dbeta,
-                       relu, frozen, dx32, dx_bf16, dresidual, n8, C / 8, 1.0f / (float)rows);
+    const int64_t n4 = rows * C / 4;
+    hipLaunchKernelGGL(bn_bwd_apply_p16_kernel, dim3(ew_grid(n4, 256, 2)), dim3(256), 0, st, dout, out, out_p16, x, mean, rstd, gamma, beta, dgamma, dbeta,
+                       relu, frozen, dx32, dx_bf16, dresidual, n4, C / 4, 1.0f / (float)rows);
     return bdetr_launch_status("bn_bwd_p16");
 }
 

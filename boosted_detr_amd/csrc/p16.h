@@ -70,3 +70,41 @@ __device__ __forceinline__ bool p16_f16_overflow(const float (&v)[8]) {
     for (int e = 0; e < 8; ++e) bad = bad || (v[e] != v[e]);
     return bad;
 }
+
+// ---- four consecutive elements per lane (element index a multiple of 4): lanes 2j / 2j+1 hold the two halves of
+// one 8-element group.  Both lanes of a pair must be active.
+__device__ __forceinline__ unsigned p16_swap_pair(unsigned v) {      // value of the neighbouring lane (lane ^ 1): DPP quad_perm [1,0,3,2]
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, false);
+}
+// Writes the pair's 32-byte group with two fully coalesced 16-byte stores: the even lane stores the hi chunk, the odd
+// lane the lo chunk, each at base + f4_index * 16 (the address a plain float4 store would use).
+template <bool F16>
+__device__ __forceinline__ void p16_store4(void* base, int64_t f4_index, float v0, float v1, float v2, float v3) {
+    unsigned h01, l01, h23, l23;
+    if (F16) { p16_split2_f16(v0, v1, h01, l01); p16_split2_f16(v2, v3, h23, l23); }
+    else     { p16_split2_bf16(v0, v1, h01, l01); p16_split2_bf16(v2, v3, h23, l23); }
+    const bool odd = (f4_index & 1) != 0;
+    const unsigned ra = p16_swap_pair(odd ? h01 : l01), rb = p16_swap_pair(odd ? h23 : l23);   // even lane receives the partner's hi, odd its lo
+    p16_u32x4 w;
+    if (odd) { w[0] = ra; w[1] = rb; w[2] = l01; w[3] = l23; }
+    else     { w[0] = h01; w[1] = h23; w[2] = ra; w[3] = rb; }
+    reinterpret_cast<p16_u32x4*>(base)[f4_index] = w;
+}
+// the lane's four values back from an f16 pair tensor
+__device__ __forceinline__ void p16_load4_f16(const void* base, int64_t f4_index, float (&v)[4]) {
+    const char* g = reinterpret_cast<const char*>(base) + (f4_index >> 1) * 32 + (f4_index & 1) * 8;
+    const unsigned h0 = reinterpret_cast<const unsigned*>(g)[0], h1 = reinterpret_cast<const unsigned*>(g)[1];
+    const unsigned l0 = reinterpret_cast<const unsigned*>(g + 16)[0], l1 = reinterpret_cast<const unsigned*>(g + 16)[1];
+    const p16_f32x2 a = __builtin_convertvector(__builtin_bit_cast(p16_f16x2, h0), p16_f32x2), b = __builtin_convertvector(__builtin_bit_cast(p16_f16x2, h1), p16_f32x2);
+    const p16_f32x2 c = __builtin_convertvector(__builtin_bit_cast(p16_f16x2, l0), p16_f32x2), d = __builtin_convertvector(__builtin_bit_cast(p16_f16x2, l1), p16_f32x2);
+    v[0] = a[0] + c[0] * (1.f / P16_LO_SCALE); v[1] = a[1] + c[1] * (1.f / P16_LO_SCALE);
+    v[2] = b[0] + d[0] * (1.f / P16_LO_SCALE); v[3] = b[1] + d[1] * (1.f / P16_LO_SCALE);
+}
+// bit e set when element e of the lane's four is > 0 in a bf16 pair tensor (the hi half decides: bf16 keeps fp32's
+// exponent range, so hi > 0 <=> x > 0 for every normal x)
+__device__ __forceinline__ unsigned p16_positive4_bf16(const void* base, int64_t f4_index) {
+    const char* g = reinterpret_cast<const char*>(base) + (f4_index >> 1) * 32 + (f4_index & 1) * 8;
+    const unsigned h0 = reinterpret_cast<const unsigned*>(g)[0], h1 = reinterpret_cast<const unsigned*>(g)[1];
+    auto pos = [](unsigned h16) { return (h16 & 0x8000u) == 0u && (h16 & 0x7FFFu) != 0u; };
+    return (pos(h0 & 0xFFFFu) ? 1u : 0u) | (pos(h0 >> 16) ? 2u : 0u) | (pos(h1 & 0xFFFFu) ? 4u : 0u) | (pos(h1 >> 16) ? 8u : 0u);
+}

@@ -262,20 +262,24 @@ def p16_pack_conv_weights(w, want_fwd=True, want_bwd=True):
     return wf, wt
 
 
-def bn_apply_p16(x2d, mean, rstd, gamma, beta, residual=None, relu=False, want_fp32=True, want_f16=True, want_bf16=True):
-    """bn_apply with P16 outputs: returns (out32 | None, out_f16 | None, out_bf16 | None)."""
+def bn_apply_p16(x2d, mean, rstd, gamma, beta, residual=None, relu=False, want_fp32=True, want_f16=True, want_bf16=True,
+                 residual_p16=False):
+    """bn_apply with P16 outputs: returns (out32 | None, out_f16 | None, out_bf16 | None).  residual_p16: `residual`
+    is the f16 pair copy of the shortcut tensor."""
     _chk(x2d, mean, rstd, gamma, beta, residual)
     rows, Cc = x2d.shape
     o32 = torch.empty_like(x2d) if want_fp32 else None
     of = torch.empty_like(x2d) if want_f16 else None
     ob = torch.empty_like(x2d) if want_bf16 else None
-    check(_lib.lib().bdetr_bn_apply_p16(_p(x2d), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(residual), int(relu), _p(o32), _p(of), _p(ob),
-                                        _p(overflow_flag()) if want_f16 else None, rows, Cc, _stream()), "bn_apply_p16")
+    check(_lib.lib().bdetr_bn_apply_p16(_p(x2d), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(residual), int(residual_p16), int(relu), _p(o32),
+                                        _p(of), _p(ob), _p(overflow_flag()) if want_f16 else None, rows, Cc, _stream()), "bn_apply_p16")
     return o32, of, ob
 
 
-def bn_bwd_p16(dout, out, x2d, mean, rstd, gamma, relu, frozen, want_residual_grad=False, dgamma=None, dbeta=None, beta=None, want_fp32=False):
-    """bn_bwd writing the input gradient as a bf16 pair: returns (dx_bf16, dx32 | None, dgamma, dbeta, dres | None)."""
+def bn_bwd_p16(dout, out, x2d, mean, rstd, gamma, relu, frozen, want_residual_grad=False, dgamma=None, dbeta=None, beta=None, want_fp32=False,
+               out_p16=False):
+    """bn_bwd writing the input gradient as a bf16 pair: returns (dx_bf16, dx32 | None, dgamma, dbeta, dres | None).
+    out_p16: the ReLU mask source `out` is the bf16 pair copy of the forward output."""
     _chk(dout, out, x2d, mean, rstd, gamma, dgamma, dbeta)
     L = _lib.lib()
     rows, Cc = x2d.shape
@@ -285,8 +289,8 @@ def bn_bwd_p16(dout, out, x2d, mean, rstd, gamma, relu, frozen, want_residual_gr
     dbeta = empty(Cc, like=x2d) if dbeta is None else dbeta
     dres = torch.empty_like(x2d) if want_residual_grad else None
     ws = empty(2 * Cc * L.bdetr_bn_bwd_chunks(rows), like=x2d)
-    check(L.bdetr_bn_bwd_p16(_p(dout), _p(out), _p(x2d), _p(mean), _p(rstd), _p(gamma), _p(beta), int(relu), int(frozen), _p(dx32), _p(dxb),
-                             _p(dgamma), _p(dbeta), _p(dres), _p(ws), rows, Cc, _stream()), "bn_bwd_p16")
+    check(L.bdetr_bn_bwd_p16(_p(dout), _p(out), int(out_p16), _p(x2d), _p(mean), _p(rstd), _p(gamma), _p(beta), int(relu), int(frozen), _p(dx32),
+                             _p(dxb), _p(dgamma), _p(dbeta), _p(dres), _p(ws), rows, Cc, _stream()), "bn_bwd_p16")
     return dxb, dx32, dgamma, dbeta, dres
 
 

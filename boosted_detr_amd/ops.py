@@ -186,9 +186,12 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
     g = K.ConvGeom(N, H, W, Cin, Kout, R, S, stride, pad)
     use_batch = training if bn_batch_stats is None else bn_batch_stats
     p16 = training and use_batch and _p16_active() and K.p16_supported(g)
-    res2d = _2d(residual) if residual is not None else None
-    x_handle = x                 # the Tape keys gradients by the handle its producer returned
-    xb = None
+    x_handle, res_handle = x, residual                 # the Tape keys gradients by the handles their producers returned
+    res_p16 = p16 and residual is not None and getattr(residual, "_p16_only", False)
+    if residual is not None and not res_p16:
+        residual = as_fp32(residual)
+    res2d = _2d(residual) if residual is not None else None     # a P16-only handle IS its f16 pair copy
+    xb = ob = None
     if p16:
         xf, xb = _packed_input(x, need_bf16=w.needs_grad)
         wf, _ = packed_weights(w, need_bwd=False)
@@ -197,7 +200,7 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
         mean, rstd = K.bn_stats(g.M, Kout, parts, bn.eps, bn.momentum, True, bn.moving_mean.value, bn.moving_var.value, like=y2d)
         fp32_out = want_fp32 or not want_p16
         o32, of, ob = K.bn_apply_p16(y2d, mean, rstd, bn.gamma.value, bn.beta.value, res2d, relu,
-                                     want_fp32=fp32_out, want_f16=want_p16, want_bf16=want_p16)
+                                     want_fp32=fp32_out, want_f16=want_p16, want_bf16=want_p16, residual_p16=res_p16)
         out2d = o32
         out = (o32 if fp32_out else of).view(N, g.OH, g.OW, Kout)
         if want_p16:
@@ -214,8 +217,11 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
         want_res = residual is not None
         if p16 and _p16_active():
             sg, sb = GradSink(bn.gamma), GradSink(bn.beta)
-            dyb, _, _, _, dres = K.bn_bwd_p16(g2d, out2d if (relu and want_res) else None, y2d, mean, rstd, bn.gamma.value, relu, False,
-                                              want_residual_grad=want_res, dgamma=sg.buf, dbeta=sb.buf, beta=bn.beta.value)
+            # ReLU mask: recomputed from y when there is no residual, else read from the forward output (fp32, or the
+            # hi halves of its bf16 pair copy when the output was never materialised in fp32)
+            mask_src = (out2d if out2d is not None else ob) if (relu and want_res) else None
+            dyb, _, _, _, dres = K.bn_bwd_p16(g2d, mask_src, y2d, mean, rstd, bn.gamma.value, relu, False, want_residual_grad=want_res,
+                                              dgamma=sg.buf, dbeta=sb.buf, beta=bn.beta.value, out_p16=mask_src is not None and out2d is None)
             sg.commit()
             sb.commit()
             dyb4 = dyb.view(N, g.OH, g.OW, Kout)
@@ -240,7 +246,8 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
                     dx = _own(K.p16_conv2d_bwd_data(dyb4, wt, g))
             return dx, (_own(dres.view(residual.shape)) if want_res else None)
         x32 = as_fp32(x)
-        dy, dres = _bn_backward(g2d, out2d, y2d, mean, rstd, bn, relu, not use_batch, want_res)
+        out32 = out2d if (out2d is not None or not (relu and want_res)) else _2d(as_fp32(out))
+        dy, dres = _bn_backward(g2d, out32, y2d, mean, rstd, bn, relu, not use_batch, want_res)
         dy4 = dy.view(N, g.OH, g.OW, Kout)
         if w.needs_grad or b.needs_grad:
             with on_side_stream(x32, dy):
@@ -270,7 +277,7 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
         return dx, dr
 
     backward.wants_acc = True
-    _rec([out], [x_handle, residual], backward)
+    _rec([out], [x_handle, res_handle], backward)
     return out
 
 

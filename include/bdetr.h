@@ -144,12 +144,14 @@ int bdetr_conv2d_bwd_weight_splitk(const bdetr_conv_desc* d);
  * (|x| >= 65504 or not finite); never cleared by the library. */
 /* BatchNormalization apply / backward of bdetr_bn_apply / bdetr_bn_bwd (same reference call sites, same fp32
  * arithmetic) with P16 outputs for the consumer convolutions: out_f16 = forward operand, out_bf16 = weight-
- * gradient operand, out32 = the fp32 tensor (residual / mask source); any of the three may be null.
- * bdetr_bn_bwd_p16 writes the input gradient as a bf16 pair (dx_bf16) and, when dx32 != null, in fp32 too. */
+ * gradient operand, out32 = the fp32 tensor; any of the three may be null.  residual_p16 != 0: `residual` is the
+ * f16 pair copy of the shortcut tensor (block outputs need not exist in fp32).  bdetr_bn_bwd_p16 writes the input
+ * gradient as a bf16 pair (dx_bf16) and, when dx32 != null, in fp32 too; out_p16 != 0: the ReLU mask source `out`
+ * is the bf16 pair copy of the forward output (its hi half has fp32's range: hi > 0 <=> value > 0). */
 int bdetr_bn_apply_p16(const float* x, const float* mean, const float* rstd, const float* gamma,
-                       const float* beta, const float* residual, int relu, float* out32, void* out_f16,
-                       void* out_bf16, int* overflow_flag, int64_t rows, int C, void* stream);
-int bdetr_bn_bwd_p16(const float* dout, const float* out, const float* x, const float* mean,
+                       const float* beta, const void* residual, int residual_p16, int relu, float* out32,
+                       void* out_f16, void* out_bf16, int* overflow_flag, int64_t rows, int C, void* stream);
+int bdetr_bn_bwd_p16(const float* dout, const void* out, int out_p16, const float* x, const float* mean,
                      const float* rstd, const float* gamma, const float* beta, int relu, int frozen,
                      float* dx32, void* dx_bf16, float* dgamma, float* dbeta, float* dresidual,
                      float* ws, int64_t rows, int C, void* stream);

@@ -141,3 +141,39 @@ def test_p16_unsupported_shapes_are_reported(cuda):
     assert not k.p16_supported(k.ConvGeom(2, 32, 32, 4, 64, 7, 7, 2, 3))          # the stem: 4 input channels
     assert not k.p16_supported(k.ConvGeom(2, 8, 8, 40, 64, 3, 3, 1, 1))           # 3x3 needs C % 32 == 0
     assert k.p16_supported(k.ConvGeom(2, 8, 8, 40, 64, 1, 1, 1, 0))
+
+
+@pytest.mark.parametrize("rows,C,relu,res", [(800, 64, True, False), (3000, 256, True, True), (100, 1024, False, False), (98, 2048, True, True), (51, 8, True, True)])
+def test_bn_p16_producers_match_the_fp32_kernels(cuda, rows, C, relu, res):
+    """bdetr_bn_apply_p16 / bdetr_bn_bwd_p16 against bdetr_bn_apply / bdetr_bn_bwd: the fp32 outputs are bit-identical,
+    the pair outputs are the bit-exact P16 image of them, and the P16 forms of the residual (f16 pair) and of the ReLU
+    mask source (bf16 pair) give the result of their fp32 counterparts."""
+    from boosted_detr_amd import kernels as k
+    x = rnd(rows, C, seed=1) * 2 + 0.5
+    gamma, beta = dev(1 + 0.1 * rnd(C, seed=2)), dev(0.1 * rnd(C, seed=3))
+    resid = rnd(rows, C, seed=6) if res else None
+    xd = dev(x)
+    parts = k.colstats(xd)
+    mean, rstd = k.bn_stats(rows, C, parts, 1.001e-5, 0.99, True, dev(torch.zeros(C)), dev(torch.ones(C)), like=xd)
+    want = k.bn_apply(xd, mean, rstd, gamma, beta, dev(resid) if res else None, relu)
+    o32, of, ob = k.bn_apply_p16(xd, mean, rstd, gamma, beta, dev(resid) if res else None, relu)
+    assert torch.equal(o32, want)
+    assert torch.equal(bits(of), p16_ref(want.cpu(), True)) and torch.equal(bits(ob), p16_ref(want.cpu(), False))
+    if res:
+        # shortcut handed over as its f16 pair: equals applying the fp32 kernel to the round-tripped shortcut
+        rf, _ = k.p16_pack(dev(resid), want_bf16=False)
+        rt = k.p16_unpack(rf, True)
+        o2, _, _ = k.bn_apply_p16(xd, mean, rstd, gamma, beta, rf, relu, want_f16=False, want_bf16=False, residual_p16=True)
+        assert torch.equal(o2, k.bn_apply(xd, mean, rstd, gamma, beta, rt, relu))
+    dout = dev(rnd(rows, C, seed=7))
+    dx, dg, db, dres = k.bn_bwd(dout, want if (relu and res) else None, xd, mean, rstd, gamma, relu, False, want_residual_grad=res, beta=beta)
+    dxb, dx32, dg2, db2, dres2 = k.bn_bwd_p16(dout, want if (relu and res) else None, xd, mean, rstd, gamma, relu, False, want_residual_grad=res,
+                                              beta=beta, want_fp32=True)
+    assert torch.equal(dx32, dx) and torch.equal(dg2, dg) and torch.equal(db2, db)
+    assert torch.equal(bits(dxb), p16_ref(dx.cpu(), False))
+    if res:
+        assert torch.equal(dres2, dres)
+        if relu:     # mask from the hi halves of the bf16 pair copy of the forward output
+            dxb3, dx33, dg3, db3, dres3 = k.bn_bwd_p16(dout, ob, xd, mean, rstd, gamma, relu, False, want_residual_grad=True, beta=beta,
+                                                       want_fp32=True, out_p16=True)
+            assert torch.equal(dx33, dx) and torch.equal(dres3, dres) and torch.equal(dg3, dg) and torch.equal(db3, db)

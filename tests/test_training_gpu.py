@@ -58,11 +58,13 @@ def test_fit_callbacks_save_load(cuda, tmp_path):
     model = small_model(dropout=0.0)       # dropout noise on a 2-image toy batch is larger than one epoch's descent
     model.compile(optimizer=SGD(CosineDecayRestarts(1e-3, 4000, m_mul=.95, alpha=.1), momentum=.9, nesterov=True, clipnorm=.1))
     ckpt = str(tmp_path / "ckpt" / "weights_{epoch:02d}")
-    hist = model.fit([batch, batch, batch], epochs=2, validation_data=[batch],
+    # 3 epochs x 8 steps: single steps of this 2-image toy problem are noisy (split-K atomics make runs differ in the
+    # last bits and the trajectory amplifies them), the epoch means over 8 steps are not
+    hist = model.fit([batch] * 8, epochs=3, validation_data=[batch],
                      callbacks=[ModelCheckpoint(ckpt, save_weights_only=True), TerminateOnNaN(), TensorBoard(str(tmp_path / "logs"))], verbose=0)
-    assert len(hist["loss"]) == 2 and all(np.isfinite(hist["loss"]))
-    assert hist["loss"][1] < hist["loss"][0]                      # it trains
-    assert model.optimizer.iterations == 2 * (3 + 1)               # test_step also trains (model.py:235-236)
+    assert len(hist["loss"]) == 3 and all(np.isfinite(hist["loss"]))
+    assert hist["loss"][2] < hist["loss"][0]                      # it trains
+    assert model.optimizer.iterations == 3 * (8 + 1)               # test_step also trains (model.py:235-236)
     path = latest_checkpoint(str(tmp_path / "ckpt"))
     assert path is not None and os.path.exists(path)
     before = model.get_weights_dict()
