@@ -21,6 +21,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
+#include <utility>
 
 using namespace bdgemm;
 
@@ -151,8 +152,12 @@ struct XXPatch {
 // ----------------------------------------------------------------------------------------
 __device__ __forceinline__ int xx_swz(int r) { return ((r & 1) << 3) | ((r >> 1) & 1); }
 
-template <int BM, int BN, int WM, int WN, class LA, class LB, bool XX, bool F16>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN <= 4 && BM * BN <= 128 * 128) ? 2 : 1)
+constexpr int lds_bytes_for(int bm, int bn, int ns) { return ns * (bm + bn) * 128 > bm * bn * 4 ? ns * (bm + bn) * 128 : bm * bn * 4; }
+
+// NS = LDS stages: the loads of K-step t + NS - 1 are issued while K-step t computes and a counted s_waitcnt
+// vmcnt leaves the younger stages in flight across the (raw) barrier.
+template <int BM, int BN, int WM, int WN, int NS, class LA, class LB, bool XX, bool F16>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && 2 * lds_bytes_for(BM, BN, NS) <= 160 * 1024) ? 2 : (WM * WN == 8 ? 2 : 1))
 void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
 {
     constexpr int NW = WM * WN, NT = NW * 64;
@@ -161,7 +166,8 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
     constexpr int NIA = A_BYTES / 1024 / NW, NIB = B_BYTES / 1024 / NW;      // 1 KiB wave-instructions per wave per stage
     static_assert(NIA >= 1 && NIB >= 1 && NIA * NW * 1024 == A_BYTES && NIB * NW * 1024 == B_BYTES, "tile / wave count mismatch");
-    constexpr int LDS_BYTES = (2 * STAGE_BYTES > BM * BN * 4) ? 2 * STAGE_BYTES : BM * BN * 4;
+    constexpr int LDS_BYTES = lds_bytes_for(BM, BN, NS);
+    static_assert(NS >= 2 && NS <= 4 && LDS_BYTES <= 160 * 1024, "LDS budget");
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
 
     const int tid = threadIdx.x;
@@ -216,23 +222,27 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
     typename LA::Step stA; typename LB::Step stB;
     if constexpr (!XX) { stA = LA::step_init(opa, r_begin); stB = LB::step_init(opb, r_begin); }
 
-    auto issue = [&](int buf, int r0) {
+    // one 1-KiB wave-instruction of the stage (l < NIA: A tile, else B tile)
+    auto issue_one = [&](int buf, int r0, auto l_c) {
+        constexpr int l = decltype(l_c)::value;
         unsigned char* sa = lds + buf * STAGE_BYTES;
-        unsigned char* sb = sa + A_BYTES;
-#pragma unroll
-        for (int t = 0; t < NIA; ++t) {
+        if constexpr (l < NIA) {
+            constexpr int t = l;
             unsigned vo;
             if constexpr (!XX) vo = LA::voff(opa, rowA[t], stA, r0, qA[t], min(r_end, opa.cols));
             else               vo = LA::voff(opa, colA[t], r0 + rrA[t], min(r_end, opa.rows));
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(sa + (t * NW + wave) * 1024), 16, (int)vo, 0, 0, 0);
-        }
-#pragma unroll
-        for (int t = 0; t < NIB; ++t) {
+        } else {
+            constexpr int t = l - NIA;
             unsigned vo;
             if constexpr (!XX) vo = LB::voff(opb, rowB[t], stB, r0, qB[t], min(r_end, opb.cols));
             else               vo = LB::voff(opb, colB[t], r0 + rrB[t], min(r_end, opb.rows));
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void*)(sb + (t * NW + wave) * 1024), 16, (int)vo, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void*)(sa + A_BYTES + (t * NW + wave) * 1024), 16, (int)vo, 0, 0, 0);
         }
+    };
+    constexpr int NLOAD = NIA + NIB;
+    auto issue_all = [&](int buf, int r0) {
+        [&]<int... L>(std::integer_sequence<int, L...>) { (issue_one(buf, r0, std::integral_constant<int, L>{}), ...); }(std::make_integer_sequence<int, NLOAD>{});
         if constexpr (!XX) { LA::step_next(opa, stA); LB::step_next(opb, stB); }
     };
 
@@ -277,7 +287,11 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
         hi[0] = h[0][0]; hi[1] = h[0][1]; hi[2] = h[1][0]; hi[3] = h[1][1];
         lo[0] = l[0][0]; lo[1] = l[0][1]; lo[2] = l[1][0]; lo[3] = l[1][1];
     };
-    auto compute = [&](int buf) {
+    // One K-step: the MFMAs of stage `buf` with the NEXT stage's loads issued between the MFMA groups, in program
+    // order (LDS-DMA writes and ds_reads may alias as far as the compiler knows, so it keeps this order): a load's
+    // issue cost (address VALU + M0 + buffer_load ... lds) then hides in the shadow of the preceding MFMAs instead of
+    // running as a serial preamble in front of them.
+    auto kstep = [&](int buf) {
         const unsigned char* tA = lds + buf * STAGE_BYTES;
         const unsigned char* tB = tA + A_BYTES;
 #pragma unroll
@@ -314,13 +328,23 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
         }
     };
 
-    // ---------------- main loop: one barrier per K-step, the next stage's loads fly under the MFMAs ----------------
+    // ---------------- main loop ----------------
+    // One barrier per K-step.  Every wave issues exactly NLOAD loads per stage, in stage order, and the loop is
+    // branch-free (past the last K-step every lane's range check fails and the loads write zeros into an idle buffer),
+    // so "all but the youngest NLOAD * (NS - 2) of my loads are done" means "my share of stage kt has landed"; the
+    // barrier then extends that to every wave's share and also says that every wave is done reading stage kt - 1,
+    // whose buffer the loads issued right after it refill.  (Loads issued early - before the MFMAs, not between
+    // them - measured faster: they have the whole K-step to land.)
     const int nk = (r_end - r_begin + BK - 1) / BK;
-    if (nk > 0) issue(0, r_begin);
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p) issue_all(p, r_begin + p * BK);
+    int buf = 0, lbuf = NS - 1;
     for (int kt = 0; kt < nk; ++kt) {
-        __syncthreads();          // vmcnt(0) + barrier: stage kt has landed for every wave, and every wave is done reading stage kt-1
-        if (kt + 1 < nk) issue((kt + 1) & 1, r_begin + (kt + 1) * BK);
-        compute(kt & 1);
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(NLOAD * (NS - 2)) : "memory");
+        issue_all(lbuf, r_begin + (kt + NS - 1) * BK);
+        kstep(buf);
+        buf = buf + 1 == NS ? 0 : buf + 1;
+        lbuf = lbuf + 1 == NS ? 0 : lbuf + 1;
     }
 
     // ---------------- epilogue ----------------
@@ -338,17 +362,32 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
 // ----------------------------------------------------------------------------------------
 // host-side dispatch
 // ----------------------------------------------------------------------------------------
-enum { T_128x128 = 0, T_128x64 = 1, T_64x64 = 2 };
+// Measured and not instantiated (tools/p16_bench.py over the ResNet-50 batch-16 layers, round 2): a 3-stage ring at
+// one 128x128 workgroup per CU (19.3 ms for all layers vs 15.3), 8-wave 256x128 tiles with 2 or 3 stages (17.3 / 17.4 ms;
+// equal on the MFMA-bound 3x3 layers, slower on the short-K 1x1 layers), next-stage loads interleaved between the MFMA
+// groups instead of issued up front (15.8 ms).  The template still takes NS and WM x WN.
+enum { T_128x128 = 0, T_128x64 = 1, T_64x64 = 2, T_COUNT = 3 };
+const int TILE_BM[T_COUNT] = {128, 128, 64};
+const int TILE_BN[T_COUNT] = {128, 64, 64};
+const int TILE_WM[T_COUNT] = {2, 2, 2};
+
+int forced_tile() {
+    static int forced = -2;
+    if (forced == -2) {
+        forced = -1;
+        if (const char* e = getenv("BDETR_STILE")) {
+            const char* names[T_COUNT] = {"128x128", "128x64", "64x64"};
+            for (int t = 0; t < T_COUNT; ++t) if (!strcmp(e, names[t])) forced = t;
+        }
+    }
+    return forced;
+}
 
 // Bigger tiles stage fewer bytes per FLOP (128x128: 32 FLOP per staged byte, 64x64: 16) but need enough
 // workgroups to fill 256 CUs x 2 resident workgroups.
 int choose_tile(int64_t I, int64_t J, int64_t z) {
-    static int forced = -2;
-    if (forced == -2) {
-        forced = -1;
-        if (const char* e = getenv("BDETR_STILE")) forced = !strcmp(e, "128x128") ? T_128x128 : !strcmp(e, "128x64") ? T_128x64 : !strcmp(e, "64x64") ? T_64x64 : -1;
-    }
-    if (forced >= 0) return (forced != T_64x64 && J < 64) ? T_64x64 : forced;
+    const int forced = forced_tile();
+    if (forced >= 0) return (J < 64 || (TILE_BN[forced] == 128 && J < 128)) ? T_64x64 : forced;
     const int64_t cus = num_cus();
     auto tiles = [&](int bm, int bn) { return cdiv64(I, bm) * cdiv64(J, bn) * z; };
     if (J % 128 == 0 && tiles(128, 128) >= cus) return T_128x128;
@@ -356,25 +395,27 @@ int choose_tile(int64_t I, int64_t J, int64_t z) {
     return T_64x64;
 }
 
-template <int BM, int BN, int WM, int WN, class LA, class LB, bool XX, bool F16>
+template <int BM, int BN, int WM, int WN, int NS, class LA, class LB, bool XX, bool F16>
 int launch_cfg(const typename LA::Op& a, const typename LB::Op& b, GemmParams g, int zdim, hipStream_t st, int kind) {
     g.tiles_i = (int)cdiv64(g.I, BM);
     g.tiles_j = (int)cdiv64(g.J, BN);
     dim3 grid(g.tiles_i * g.tiles_j, 1, zdim);
     g.vec_store = (g.J % 4 == 0) && (g.ldc % 4 == 0) && aligned16(g.c);
     const bool prof = g_prof_on;
-    if (prof) prof_begin(st, 2.0 * (double)g.I * (double)g.J * (double)g.R, g.I, g.J, g.R, zdim, BM, BN,
+    if (prof) prof_begin(st, 2.0 * (double)g.I * (double)g.J * (double)g.R, g.I, g.J, g.R, zdim, BM, BN * 10 + NS,
                          (F16 ? AR_P16_F16 : AR_P16_BF16) * 10000 + kind);
-    hipLaunchKernelGGL((sgemm_kernel<BM, BN, WM, WN, LA, LB, XX, F16>), grid, dim3(WM * WN * 64), 0, st, a, b, g);
+    hipLaunchKernelGGL((sgemm_kernel<BM, BN, WM, WN, NS, LA, LB, XX, F16>), grid, dim3(WM * WN * 64), 0, st, a, b, g);
     if (prof) prof_end(st);
     return bdetr_launch_status("sgemm");
 }
 
 template <class LA, class LB, bool XX, bool F16>
 int launch_any(const typename LA::Op& a, const typename LB::Op& b, const GemmParams& g, int zdim, hipStream_t st, int kind, int tile) {
-    if (tile == T_128x128) return launch_cfg<128, 128, 2, 2, LA, LB, XX, F16>(a, b, g, zdim, st, kind);
-    if (tile == T_128x64)  return launch_cfg<128, 64, 2, 2, LA, LB, XX, F16>(a, b, g, zdim, st, kind);
-    return launch_cfg<64, 64, 2, 2, LA, LB, XX, F16>(a, b, g, zdim, st, kind);
+    switch (tile) {
+        case T_128x128:    return launch_cfg<128, 128, 2, 2, 2, LA, LB, XX, F16>(a, b, g, zdim, st, kind);
+        case T_128x64:     return launch_cfg<128, 64, 2, 2, 2, LA, LB, XX, F16>(a, b, g, zdim, st, kind);
+        default:           return launch_cfg<64, 64, 2, 2, 2, LA, LB, XX, F16>(a, b, g, zdim, st, kind);
+    }
 }
 
 constexpr int64_t MAX_OPERAND_ELEMS = (int64_t)(NUM_RECORDS / 4) - 64;
@@ -419,7 +460,7 @@ static int fwd_tile(const bdetr_conv_desc* d) { return choose_tile((int64_t)d->N
 extern "C" int bdetr_p16_conv2d_fwd_stat_chunks(const bdetr_conv_desc* d) {
     if (check_conv(d, "bdetr_p16_conv2d_fwd_stat_chunks")) return -1;
     const int t = fwd_tile(d);
-    return (int)cdiv64((int64_t)d->N * d->OH * d->OW, t == T_64x64 ? 64 : 128) * 2;      // tiles_i * WM
+    return (int)cdiv64((int64_t)d->N * d->OH * d->OW, TILE_BM[t]) * TILE_WM[t];          // tiles_i * WM
 }
 
 extern "C" int bdetr_p16_conv2d_fwd(const void* x_f16, const void* w_f16, const float* bias, float* y,
@@ -478,15 +519,17 @@ extern "C" int bdetr_p16_conv2d_bwd_data(const void* dy_bf16, const void* wt_bf1
 
 static int wgrad_tile(const bdetr_conv_desc* d) {
     const int64_t Kd = (int64_t)d->R * d->S * d->C;
-    return (d->K % 128 == 0 && Kd % 128 == 0) ? T_128x128 : T_64x64;
+    if (!(d->K % 128 == 0 && Kd % 128 == 0)) return T_64x64;
+    const int forced = forced_tile();
+    return (forced >= 0 && TILE_BN[forced] == 128 && (TILE_BM[forced] != 256 || d->K % 256 == 0)) ? forced : T_128x128;
 }
 
 extern "C" int bdetr_p16_conv2d_bwd_weight_splitk(const bdetr_conv_desc* d) {
     if (check_conv(d, "bdetr_p16_conv2d_bwd_weight_splitk")) return -1;
     const int M = d->N * d->OH * d->OW;
     const int64_t Kd = (int64_t)d->R * d->S * d->C;
-    const int bm = wgrad_tile(d) == T_128x128 ? 128 : 64;
-    const int64_t tiles = cdiv64(d->K, bm) * cdiv64(Kd, bm);
+    const int t = wgrad_tile(d);
+    const int64_t tiles = cdiv64(d->K, TILE_BM[t]) * cdiv64(Kd, TILE_BN[t]);
     int64_t sk = cdiv64(3LL * num_cus(), tiles);
     const int64_t maxsk = cdiv64(M, 8 * BK);       // keep >= 8 stages per split
     if (sk > maxsk) sk = maxsk;
