@@ -83,7 +83,8 @@ SIGNATURES = {
     "bdetr_colsum_chunks": (I, [L]),
     "bdetr_colsum": (I, [P, L, I, P, P, P]),
     "bdetr_colstats": (I, [P, L, I, P, P, P]),
-    "bdetr_bn_stats": (I, [P, L, I, P, P, I, F, F, I, P, P, P, P, P, P]),
+    "bdetr_bn_stats": (I, [P, L, I, P, P, I, F, F, I, P, P, P, P, P, P, P]),
+    "bdetr_flag_nonfinite": (I, [P, L, P, P]),
     "bdetr_bn_stats_fold_rows": (I, []),
     "bdetr_bn_stats_frozen": (I, [P, P, I, F, P, P, P]),
     "bdetr_bn_apply": (I, [P, P, P, P, P, P, I, P, L, I, P]),
@@ -117,7 +118,7 @@ SIGNATURES = {
     "bdetr_set_loss": (I, [C.POINTER(LossDesc), P, P, P, P, P, P, P, P, P, P, P, P, F, P]),
     "bdetr_match_to_mask": (I, [P, P, I, I, I, P]),
     "bdetr_sgd_slab_elems": (I, []),
-    "bdetr_sgd_nesterov_clipnorm": (I, [P, P, I, P, P, I, P, P, P, F, F, F, P]),
+    "bdetr_sgd_nesterov_clipnorm": (I, [P, P, I, P, P, I, P, P, P, F, F, F, P, P]),
 }
 
 
@@ -147,7 +148,7 @@ def lib():
         fn = getattr(h, name)          # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if h.bdetr_abi_version() != 2:
+    if h.bdetr_abi_version() != 3:
         raise BdetrError("libbdetr.so ABI version mismatch; rebuild")
     _lib = h
     return _lib

@@ -188,6 +188,11 @@ __global__ __launch_bounds__(256) void tokens_prepare_kernel(const int* __restri
     }
 }
 
+__global__ __launch_bounds__(256) void flag_nonfinite_kernel(const float* __restrict__ x, int64_t n, int* __restrict__ flag) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        if (!(fabsf(x[i]) <= 3.0e38f)) *flag = 1;
+}
+
 }  // namespace
 
 extern "C" int bdetr_tokens_prepare(const int* cat_ids, const int* att_ids, int64_t rows, int slots, int C, int A,
@@ -195,6 +200,12 @@ extern "C" int bdetr_tokens_prepare(const int* cat_ids, const int* att_ids, int6
     BDETR_CHECK_ARG(cat_ids && att_ids && cat_out && att_hot && rows > 0 && slots >= 0 && C > 1 && A > 1, "bdetr_tokens_prepare: bad arguments");
     hipLaunchKernelGGL(tokens_prepare_kernel, dim3(ew_grid(rows, 256, 1)), dim3(256), 0, (hipStream_t)stream, cat_ids, att_ids, rows, slots, C, A, cat_out, att_hot);
     return bdetr_launch_status("tokens_prepare");
+}
+
+extern "C" int bdetr_flag_nonfinite(const float* x, int64_t n, int* flag, void* stream) {
+    BDETR_CHECK_ARG(x && flag && n > 0, "bdetr_flag_nonfinite: bad arguments");
+    hipLaunchKernelGGL(flag_nonfinite_kernel, dim3(ew_grid(n, 256, 4)), dim3(256), 0, (hipStream_t)stream, x, n, flag);
+    return bdetr_launch_status("flag_nonfinite");
 }
 
 extern "C" int bdetr_image_prep(const float* in, int B, int h, int w, float* out, int H, int W, void* stream) {

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void colreduce2_kernel(F f, int64_t rows, int 
 // sum partials [nparts][C] in fp64, fixed order: 32 columns x 8 phases per block
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ psum, const float* __restrict__ psq, int nparts,
                                                           int64_t rows, int C, float eps, float momentum, int bessel,
-                                                          float* mean, float* rstd, float* mmean, float* mvar) {
+                                                          float* mean, float* rstd, float* mmean, float* mvar, int* guard) {
     __shared__ double s1[256], s2[256];
     const int cx = threadIdx.x & 31, py = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cx;
@@ -67,7 +67,14 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
         if (var < 0) var = 0;
         mean[c] = (float)m;
         rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-        if (mmean != nullptr) {
+        // guard: a forward that left the f16 pair's range (flag set by an upstream producer) or produced non-finite
+        // statistics must not poison the moving statistics - the host redoes such a step on the exact-fp32 forward
+        bool ok = true;
+        if (guard != nullptr) {
+            if (!(fabs(m) <= 3.0e38) || !(var <= 3.0e38)) *guard = 1;      // catches NaN too
+            ok = *guard == 0;
+        }
+        if (mmean != nullptr && ok) {
             double vm = (bessel && rows > 1) ? var * ((double)rows / (double)(rows - 1)) : var;
             mmean[c] = mmean[c] * momentum + (float)m * (1.f - momentum);
             mvar[c] = mvar[c] * momentum + (float)vm * (1.f - momentum);
@@ -495,7 +502,7 @@ extern "C" int bdetr_bn_stats_fold_rows(void) { return BN_FOLD; }
 
 extern "C" int bdetr_bn_stats(const float* x, int64_t rows, int C, const float* part_sum, const float* part_sq,
                               int nparts, float eps, float momentum, int bessel,
-                              float* mean, float* rstd, float* moving_mean, float* moving_var, float* fold_ws, void* stream) {
+                              float* mean, float* rstd, float* moving_mean, float* moving_var, float* fold_ws, int* guard_flag, void* stream) {
     BDETR_CHECK_ARG(mean && rstd && rows > 0 && C > 0, "bdetr_bn_stats: bad arguments");
     BDETR_CHECK_ARG(part_sum != nullptr && part_sq != nullptr && nparts > 0,
                     "bdetr_bn_stats: partial sums required (use bdetr_colstats to produce them from x)");
@@ -508,7 +515,7 @@ extern "C" int bdetr_bn_stats(const float* x, int64_t rows, int C, const float* 
         part_sum = fa; part_sq = fb; nparts = BN_FOLD;
     }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, part_sum, part_sq, nparts, rows, C, eps, momentum, bessel,
-                       mean, rstd, moving_mean, moving_var);
+                       mean, rstd, moving_mean, moving_var, guard_flag);
     return bdetr_launch_status("bn_finalize");
 }
 

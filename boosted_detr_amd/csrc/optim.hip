@@ -41,7 +41,8 @@ __global__ __launch_bounds__(256) void norm_final_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void sgd_apply_kernel(const uint64_t* __restrict__ ptrs, const int64_t* __restrict__ sizes,
                                                         const int64_t* __restrict__ slab_tensor, const int64_t* __restrict__ slab_first,
                                                         const float* __restrict__ norms, const float* __restrict__ lr_p,
-                                                        float momentum, float clipnorm, float grad_scale) {
+                                                        float momentum, float clipnorm, float grad_scale, const int* __restrict__ skip_flag) {
+    if (skip_flag != nullptr && *skip_flag != 0) return;      // the step overflowed the f16 pair range / went non-finite: apply nothing
     const int64_t t = slab_tensor[blockIdx.x];
     const int64_t off = (blockIdx.x - slab_first[t]) * (int64_t)SLAB;
     float* w = reinterpret_cast<float*>(ptrs[3 * t + 0]);
@@ -71,12 +72,12 @@ extern "C" int bdetr_sgd_slab_elems(void) { return SLAB; }
 extern "C" int bdetr_sgd_nesterov_clipnorm(const uint64_t* ptrs, const int64_t* sizes, int ntensors,
                                            const int64_t* slab_tensor, const int64_t* slab_first, int nslabs,
                                            float* partial, float* norms, const float* lr, float momentum,
-                                           float clipnorm, float grad_scale, void* stream) {
+                                           float clipnorm, float grad_scale, const int* skip_flag, void* stream) {
     BDETR_CHECK_ARG(ptrs && sizes && slab_tensor && slab_first && partial && norms && lr && ntensors > 0 && nslabs > 0,
                     "bdetr_sgd_nesterov_clipnorm: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(sqnorm_kernel, dim3(nslabs), dim3(256), 0, st, ptrs, sizes, slab_tensor, slab_first, partial);
     hipLaunchKernelGGL(norm_final_kernel, dim3((ntensors + 255) / 256), dim3(256), 0, st, partial, slab_first, ntensors, norms);
-    hipLaunchKernelGGL(sgd_apply_kernel, dim3(nslabs), dim3(256), 0, st, ptrs, sizes, slab_tensor, slab_first, norms, lr, momentum, clipnorm, grad_scale);
+    hipLaunchKernelGGL(sgd_apply_kernel, dim3(nslabs), dim3(256), 0, st, ptrs, sizes, slab_tensor, slab_first, norms, lr, momentum, clipnorm, grad_scale, skip_flag);
     return bdetr_launch_status("sgd_nesterov_clipnorm");
 }

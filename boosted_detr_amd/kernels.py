@@ -230,6 +230,22 @@ def overflow_flag() -> torch.Tensor:
     return _OVERFLOW[0]
 
 
+def flag_nonfinite(x: torch.Tensor) -> None:
+    """Set the step's range guard when x holds a non-finite value (the loss vectors: a NaN born in a kernel without
+    its own range check, e.g. the in-kernel split-fp16 products of the transformer layers)."""
+    _chk(x)
+    check(_lib.lib().bdetr_flag_nonfinite(_p(x), x.numel(), _p(overflow_flag()), _stream()), "flag_nonfinite")
+
+
+def read_and_clear_overflow() -> bool:
+    """Host read of the range guard (synchronises the device)."""
+    f = overflow_flag()
+    tripped = bool(int(f.item()))
+    if tripped:
+        f.zero_()
+    return tripped
+
+
 def p16_supported(g: ConvGeom) -> bool:
     d = g.desc()
     return bool(_lib.lib().bdetr_p16_supported(C.byref(d)))
@@ -442,7 +458,7 @@ def bn_stats(rows, Cc, parts, eps, momentum, bessel, moving_mean, moving_var, li
     fold = L.bdetr_bn_stats_fold_rows()
     ws = empty(2 * fold * Cc, like=like) if n > 4 * fold else None
     check(L.bdetr_bn_stats(None, rows, Cc, _p(psum), _p(psq), n, eps, momentum, int(bessel), _p(mean), _p(rstd),
-                           _p(moving_mean), _p(moving_var), _p(ws), _stream()), "bn_stats")
+                           _p(moving_mean), _p(moving_var), _p(ws), _p(overflow_flag()) if like.is_cuda else None, _stream()), "bn_stats")
     return mean, rstd
 
 

@@ -122,13 +122,15 @@ class SGD:
                 gv.copy_(v.grad.view(gv.shape))          # D2D memcpy (plumbing): first step / shared-variable temporaries
             v.grad = gv
 
-    def apply_gradients(self, grad_scale: float = 1.0) -> None:
+    def apply_gradients(self, grad_scale: float = 1.0, skip_flag: Optional[torch.Tensor] = None) -> None:
+        """skip_flag: device int32; while it is non-zero the update is not applied (the step's range guard)."""
         self.d_lr.fill_(self.current_lr())
         st = torch.cuda.current_stream().cuda_stream
         _lib.check(_lib.lib().bdetr_sgd_nesterov_clipnorm(
             self.d_ptrs.data_ptr(), self.d_sizes.data_ptr(), len(self.vars), self.d_slab_tensor.data_ptr(),
             self.d_slab_first.data_ptr(), self.nslabs, self.d_partial.data_ptr(), self.d_norms.data_ptr(),
-            self.d_lr.data_ptr(), self.momentum, self.clipnorm, float(grad_scale), st), "sgd")
+            self.d_lr.data_ptr(), self.momentum, self.clipnorm, float(grad_scale),
+            skip_flag.data_ptr() if skip_flag is not None else None, st), "sgd")
         bump_weights_version()
         self.iterations += 1
 
@@ -168,6 +170,11 @@ class DataParallel:
     def barrier(self) -> None:
         if self.world > 1:
             self.dist.barrier()
+
+    def any_(self, flag: torch.Tensor) -> None:
+        """flag <- max over replicas (the range guard: a replica that skips its update must make all of them skip)."""
+        if self.world > 1:
+            self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX)
 
 
 # ----------------------------------------------------------------------------------------
@@ -241,6 +248,14 @@ class Model(Layer):
         # variable BDETR_GEMM_PRECISION, when set, wins (None = leave the library's mode alone).
         self.train_gemm_precision = None if os.environ.get("BDETR_GEMM_PRECISION") else "split"
         self.validate_matching = False      # fit() turns this on: it synchronises every step anyway (host logging)
+        # Range guard of the 'split' policy: the f16 pairs of its forward products hold |x| < 65504, the reference's
+        # fp32 does not overflow there.  Producers raise a device flag instead of feeding NaN downstream; while it is
+        # up the optimizer applies nothing and moving statistics stay put.  Every `guard_check_every` steps (every
+        # step under fit(), which synchronises anyway) the host reads the flag and redoes the batch on the
+        # exact-fp32 forward ('mixed').
+        self.guard_check_every = 50
+        self.range_redos = 0
+        self._guard_count = 0
 
     # -- Keras bookkeeping -----------------------------------------------------------------
     def add_loss(self, loss) -> None:
@@ -301,7 +316,28 @@ class Model(Layer):
         join_side_stream()                                      # weight-gradient GEMMs ran on the side stream
         return y_pred
 
+    def _guarded(self) -> bool:
+        return (self.train_gemm_precision or K.get_gemm_precision()) == "split"
+
     def train_step(self, data: dict) -> Dict[str, torch.Tensor]:
+        logs = self._train_step_once(data)
+        if self._guarded() and self.guard_check_every:
+            self._guard_count += 1
+            if self._guard_count % self.guard_check_every == 0 and K.read_and_clear_overflow():       # host sync
+                import sys
+                self.range_redos += 1
+                print(f"[boosted_detr_amd] step {self.steps_done}: the split-fp16 forward left its range (|x| >= 65504) or went "
+                      f"non-finite; no update was applied since the flag rose - redoing this batch on the exact-fp32 forward", file=sys.stderr)
+                self.steps_done -= 1                     # the guarded attempt applied nothing: it is not a step
+                self.optimizer.iterations -= 1
+                keep, self.train_gemm_precision = self.train_gemm_precision, "mixed"
+                try:
+                    logs = self._train_step_once(data)
+                finally:
+                    self.train_gemm_precision = keep
+        return logs
+
+    def _train_step_once(self, data: dict) -> Dict[str, torch.Tensor]:
         if self.optimizer is None:
             raise RuntimeError("call compile(optimizer=...) before fit/train_step")
         if self._dp is not None and not getattr(self, "_dp_synced", True) and self.built_variables():
@@ -319,9 +355,16 @@ class Model(Layer):
             MatchingAssignment.validate(self.loss_fn.last_match, self.loss_fn.last_num_objects, self.num_object_preds)
         tv = self.trainable_variables
         self.optimizer.stage_gradients(tv)
+        guard = None
+        if self._guarded():
+            for root in self._loss_roots:
+                K.flag_nonfinite(root)
+            guard = K.overflow_flag()
         if self._dp is not None:
             self._dp.allreduce_(self.optimizer.flat_grad)
-        self.optimizer.apply_gradients()
+            if guard is not None:
+                self._dp.any_(guard)
+        self.optimizer.apply_gradients(skip_flag=guard)
         self.steps_done += 1
         return self.step_logs()
 
@@ -352,6 +395,7 @@ class Model(Layer):
         history = {"loss": []}
         self.stop_training = False
         self.validate_matching = True
+        self.guard_check_every = 1            # every step ends in a host read of the logs anyway
         for epoch in range(epochs):
             t0, n, sums = time.time(), 0, {}
             for step, batch in enumerate(x):

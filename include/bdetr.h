@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define BDETR_ABI_VERSION 2
+#define BDETR_ABI_VERSION 3
 
 int         bdetr_abi_version(void);
 const char* bdetr_last_error(void);
@@ -215,7 +215,14 @@ int bdetr_colstats(const float* x, int64_t rows, int C, float* part_sum, float* 
  * (momentum; bessel!=0 uses the unbiased variance for the moving estimate).  x is unused. */
 int bdetr_bn_stats(const float* x, int64_t rows, int C, const float* part_sum, const float* part_sq,
                    int nparts, float eps, float momentum, int bessel,
-                   float* mean, float* rstd, float* moving_mean, float* moving_var, float* fold_ws, void* stream);
+                   float* mean, float* rstd, float* moving_mean, float* moving_var, float* fold_ws,
+                   int* guard_flag, void* stream);
+/* guard_flag (device int*, may be null): the step's range guard.  The P16-f16 producers set it when a forward
+ * activation leaves the f16 pair's range; bn_stats sets it when the batch statistics are not finite and skips
+ * the moving-statistics update while it is set; bdetr_flag_nonfinite sets it for a non-finite loss; the
+ * optimizer applies nothing while it is set.  The host reads and clears it and redoes the step on the
+ * exact-fp32 forward (the reference's fp32 arithmetic has no such range limit). */
+int bdetr_flag_nonfinite(const float* x, int64_t n, int* flag, void* stream);
 /* fold_ws (optional): 2*C*bdetr_bn_stats_fold_rows() floats; lets bn_stats pre-reduce thousands of
  * epilogue partial rows with a wide grid before the fp64 finalise */
 int bdetr_bn_stats_fold_rows(void);
@@ -350,7 +357,7 @@ int bdetr_sgd_slab_elems(void);
 int bdetr_sgd_nesterov_clipnorm(const uint64_t* ptrs, const int64_t* sizes, int ntensors,
                                 const int64_t* slab_tensor, const int64_t* slab_first, int nslabs,
                                 float* partial, float* norms, const float* lr, float momentum,
-                                float clipnorm, float grad_scale, void* stream);
+                                float clipnorm, float grad_scale, const int* skip_flag, void* stream);
 
 #ifdef __cplusplus
 }

@@ -17,7 +17,8 @@ pytestmark = pytest.mark.gpu
 TOL = {"fp32": 2e-5, "bf16x3": 6e-5, "split": 6e-5}          # gradient products (and everything under bf16x3)
 TOL_FWD = {"fp32": 2e-5, "bf16x3": 6e-5, "split": 2e-5}      # forward products: split = fp16x3, fp32-grade
 
-LINEARS = [(300, 256, 256), (6400, 256, 1024), (1600, 1024, 256), (130, 52, 48), (4000, 64, 64), (25600, 128, 512)]
+LINEARS = [(300, 256, 256), (6400, 256, 1024), (1600, 1024, 256), (130, 52, 48), (4000, 64, 64), (25600, 128, 512),
+           (1600, 1024, 82), (1600, 256, 3), (1600, 256, 4)]          # the heads: unaligned 82- / 3-wide outputs, the narrow 128x32 tile
 BIG_LINEARS = [(102400, 256, 128), (25600, 1024, 256), (6400, 2048, 512)]
 CONVS = [(2, 20, 20, 64, 64, 3, 1, 1), (2, 20, 20, 256, 128, 1, 2, 0), (1, 9, 11, 128, 32, 3, 1, 1),
          (3, 7, 7, 512, 2048, 1, 1, 0), (4, 40, 40, 256, 256, 3, 1, 1), (2, 32, 32, 4, 64, 7, 2, 3)]

@@ -224,3 +224,42 @@ def test_recompile_and_unfreeze_do_not_reuse_stale_gradient_slices(cuda):
         if not v.trainable:
             v.assign(params[v.name])
     same(_grads_after_one_step(m, batch), want)
+
+
+def test_range_guard_redoes_an_overflowing_step_on_the_fp32_forward(cuda):
+    """A training-mode activation beyond 65504 (here: a BatchNorm beta of 1e5 inside the backbone) is finite in the
+    reference's fp32 arithmetic but outside the f16 pairs of the 'split' forward.  The step must not emit NaN or
+    touch the weights / moving statistics with garbage: the producers raise the range guard, the optimizer applies
+    nothing, and train_step redoes the batch on the exact-fp32 forward - giving what a 'mixed' step gives."""
+    from boosted_detr_amd import kernels as k
+    from boosted_detr_amd.training import SGD
+    from oracle import detr_oracle as O
+    cfg, batch = small_batch()
+    params = O.make_params(cfg, seed=1)
+    name = "EncoderBackbone/resnet50/conv2_block1_1_bn/beta"
+    params[name] = np.full_like(params[name], 1e5)
+
+    def fresh(policy):
+        m = small_model()
+        m.compile(optimizer=SGD(1e-3, momentum=0.9, nesterov=True, clipnorm=0.1))
+        m.train_gemm_precision = "mixed"
+        m.forward_backward(batch)                       # build (on the range-safe policy)
+        m.set_weights_dict(params)
+        m.train_gemm_precision = policy
+        m.guard_check_every = 1
+        return m
+
+    k.read_and_clear_overflow()
+    ref = fresh("mixed")
+    want = ref.logs_to_host(ref.train_step(batch))
+    assert ref.range_redos == 0 and np.isfinite(want["loss"])
+    m = fresh("split")
+    got = m.logs_to_host(m.train_step(batch))
+    assert m.range_redos == 1 and not k.read_and_clear_overflow()
+    assert np.isfinite(got["loss"]) and abs(got["loss"] - want["loss"]) <= 1e-4 * abs(want["loss"])
+    a, b = m.get_weights_dict(), ref.get_weights_dict()
+    for key in a:
+        assert np.isfinite(a[key]).all(), key
+        scale = np.abs(b[key]).max() + 1e-12
+        assert np.abs(a[key] - b[key]).max() <= 1e-4 * scale, key      # weights AND moving statistics: one update, from the redo
+    assert m.optimizer.iterations == 1 and m.steps_done == 1           # the guarded attempt applied nothing and is not counted
