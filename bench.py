@@ -182,6 +182,7 @@ def main():
     ap.add_argument("--learners", type=int, default=3)
     ap.add_argument("--fashionpedia", action="store_true", help="46 categories / 294 attributes, attribute_weight 1.0")
     ap.add_argument("--backbone", default="ResNet", choices=["ResNet", "ResNet101"], help="configs[4]: ResNet101 (no reference counterpart)")
+    ap.add_argument("--no-batch32", action="store_true", help="skip the secondary measurement at configs[3]'s per-GPU batch (32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -297,6 +298,31 @@ def main():
                     "measured": f"hipEvents around every launch over {args.steps} steps run right after the timed region, with the "
                                 f"weight-gradient GEMMs in stream order (no side-stream overlap) so that launches do not time-share "
                                 f"the chip ({prof_wall / args.steps * 1e3:.2f} ms/step in that mode)"}
+    # Secondary measurement at BASELINE.json configs[3]'s per-GPU batch (global 256 on 8 GPUs = 32 per GPU): the same
+    # model and step, a batch of 32 resident images per rank.  `value` above stays the fixed 16-per-GPU weak-scaling
+    # series; this one is reported next to it in config.configs3.
+    b32 = None
+    if not args.no_batch32 and is_config2(args) and args.batch != 32:
+        host32 = make_batch(32, args.image, args.image, 100, 82, seed=4321 + rank)
+        batch32 = {"image": to_device(host32["image"]), "category": to_device(host32["category"], torch.int32),
+                   "attribute": to_device(host32["attribute"], torch.int32),
+                   "bbox": to_device(host32["bbox"]), "num_objects": to_device(host32["num_objects"], torch.int32)}
+        for _ in range(2):
+            model.train_step(batch32)
+        barrier()
+        t2 = time.perf_counter()
+        k32 = max(3, args.steps // 2)
+        for _ in range(k32):
+            model.train_step(batch32)
+        barrier()
+        e32 = time.perf_counter() - t2
+        if dist is not None:
+            t = torch.tensor([e32], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e32 = float(t.item())
+        b32 = {"per_gpu_batch": 32, "global_batch": 32 * world, "steps": k32, "ms_per_step": round(e32 / k32 * 1e3, 3),
+               "value": round(32 * world * k32 / e32, 2), "unit": "images/s"}
+        del batch32
     if world > 1:
         barrier()
     if dist is not None:
@@ -315,7 +341,8 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": dtype_note(model), "arithmetic": arithmetic_note(model), "data": "synthetic",
             "config": {"workload": workload_name(args), "per_gpu_batch": args.batch, "global_batch": global_batch,
-                       "parallelism": f"dp{world}", "gflop_per_image_algorithmic": GFLOP_PER_IMAGE if is_config2(args) else None},
+                       "parallelism": f"dp{world}", "gflop_per_image_algorithmic": GFLOP_PER_IMAGE if is_config2(args) else None,
+                       "configs3": b32},
             "tflops_algorithmic": round(value * GFLOP_PER_IMAGE / 1e3, 2) if is_config2(args) else None,
             "final_loss": round(logs.get("loss", float("nan")), 4),
             "roofline": roof,

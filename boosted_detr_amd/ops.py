@@ -59,6 +59,15 @@ def set_live_flat_grad(flat: Optional[torch.Tensor]) -> None:
     _live_flat_grad[0] = flat
 
 
+_grad_ready_hook = [None]
+
+
+def set_grad_ready_hook(fn) -> None:
+    """fn(var) is called after every gradient contribution to a parameter has been enqueued (data-parallel training
+    launches a bucket's all-reduce once all of its gradients are complete and live in the flat buffer)."""
+    _grad_ready_hook[0] = fn
+
+
 class GradSink:
     """Where a backward kernel writes one parameter's gradient.
 
@@ -87,6 +96,8 @@ class GradSink:
                 v.grad = self.buf
             else:
                 K.axpy_(1.0, self.buf.view(v.grad.shape), v.grad)
+        if self.mode != "drop" and _grad_ready_hook[0] is not None:
+            _grad_ready_hook[0](v)
 
 
 # ----------------------------------------------------------------------------------------

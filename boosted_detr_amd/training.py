@@ -139,17 +139,29 @@ class SGD:
 # data parallelism (one process per GPU; RCCL all-reduce of the flat gradient buffer)
 # ----------------------------------------------------------------------------------------
 class DataParallel:
-    """Replicas keep per-replica BN statistics, matcher and normaliser exactly like the reference
-    under MirroredStrategy (parameters.py:74); the only collective is the gradient all-reduce."""
+    """Replicas keep per-replica BN statistics, matcher and normaliser exactly like the reference under
+    MirroredStrategy (parameters.py:74); the only collective is the gradient all-reduce (SUM; the loss is already
+    scaled by 1/R), issued through torch.distributed - backend "nccl" is RCCL over xGMI on ROCm.
 
-    BUCKET_ELEMS = 8 * 1024 * 1024      # 32 MB fp32 buckets: few, large collectives for point-to-point xGMI
+    The flat gradient buffer is cut into ~32 MB buckets (few, large collectives: xGMI is point-to-point and a ring
+    is per-link bound).  Buckets are numbered from the END of the buffer, i.e. in the order the backward pass
+    completes them; ``grad_ready`` (called by ops.GradSink when a parameter gradient has been written in place)
+    counts a bucket down and launches its all-reduce as soon as its last gradient has been enqueued, so the
+    collectives overlap the rest of the backward pass.  Whatever was not launched early (first step, shared or
+    temporary gradients) goes out in ``finish``."""
+
+    BUCKET_ELEMS = 8 * 1024 * 1024      # 32 MB fp32 buckets
 
     def __init__(self):
         import torch.distributed as dist
         self.dist = dist
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.overlap = os.environ.get("BDETR_DP_OVERLAP", "1") != "0"
+        self._flat = None
+        self._comm_stream = None
 
+    # -- plain path (also the gloo CPU tests) ---------------------------------------------------------------
     def allreduce_(self, flat: torch.Tensor) -> None:
         if self.world == 1:
             return
@@ -158,6 +170,108 @@ class DataParallel:
             handles.append(self.dist.all_reduce(flat[o: o + self.BUCKET_ELEMS], op=self.dist.ReduceOp.SUM, async_op=True))
         for h in handles:
             h.wait()
+
+    # -- overlapped path ---------------------------------------------------------------------------------------
+    def prepare(self, optimizer: "SGD") -> None:
+        """Bucket table for the optimizer's current flat buffer: bucket b covers [lo, hi) elements, counted from the end."""
+        flat = optimizer.flat_grad
+        if self._flat is flat:
+            return
+        self._flat = flat
+        self._expected = None          # contributions per variable and step, learnt from the first (non-overlapped) step
+        n = flat.numel()
+        self._bounds = []
+        hi = n
+        while hi > 0:
+            lo = max(0, hi - self.BUCKET_ELEMS)
+            self._bounds.append((lo, hi))
+            hi = lo
+        base = flat.data_ptr()
+        self._var_bucket, self._bucket_size = {}, [0] * len(self._bounds)
+        for v in optimizer.vars:
+            off = (v.grad_buf.data_ptr() - base) // 4
+            b = next(i for i, (lo, hi_) in enumerate(self._bounds) if lo <= off < hi_)
+            # a tensor that straddles a boundary belongs to the LATER-finishing (lower) bucket as well: count it in both
+            last = off + v.grad_buf.numel() - 1
+            b2 = next(i for i, (lo, hi_) in enumerate(self._bounds) if lo <= last < hi_)
+            self._var_bucket[id(v)] = (b, b2)
+            for k in {b, b2}:
+                self._bucket_size[k] += 1
+
+    def begin_step(self, optimizer: "SGD", main_stream, side_stream) -> None:
+        self._active = False
+        if self.world == 1 or not self.overlap or getattr(optimizer, "flat_grad", None) is None:
+            return
+        self.prepare(optimizer)
+        self._seen = {}
+        self._pending = list(self._bucket_size)
+        self._launched = [False] * len(self._bounds)
+        self._handles = []
+        self._main, self._side = main_stream, side_stream
+        if self._comm_stream is None and self._flat.is_cuda:
+            self._comm_stream = torch.cuda.Stream(device=self._flat.device)
+        self._active = True
+
+    def _launch(self, b: int) -> None:
+        lo, hi = self._bounds[b]
+        self._launched[b] = True
+        if self._flat.is_cuda:
+            # the bucket's gradients were written on the main stream (normalisation / bias gradients) and on the side
+            # stream (weight-gradient GEMMs): the collective waits for both, neither of them waits for it
+            comm = self._comm_stream
+            for st in (self._main, self._side):
+                if st is not None:
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    comm.wait_event(ev)
+            with torch.cuda.stream(comm):
+                self._handles.append(self.dist.all_reduce(self._flat[lo:hi], op=self.dist.ReduceOp.SUM, async_op=True))
+        else:
+            self._handles.append(self.dist.all_reduce(self._flat[lo:hi], op=self.dist.ReduceOp.SUM, async_op=True))
+
+    def grad_ready(self, var: Variable) -> None:
+        """One gradient contribution to `var` has been enqueued.  A variable may receive several per step (shared layers:
+        the re-tiled decoder queries of BoostedDETR); its bucket may only go out after the last one, so the first step
+        after (re)building the buffer runs without early launches and records how many each variable gets."""
+        if not getattr(self, "_active", False):
+            return
+        k = id(var)
+        self._seen[k] = self._seen.get(k, 0) + 1
+        if self._expected is None:
+            return
+        bs = self._var_bucket.get(k)
+        if bs is None or getattr(var, "_grad_flat", None) is not self._flat:
+            return
+        if self._seen[k] > self._expected.get(k, 0):
+            if any(self._launched[b] for b in set(bs)):
+                raise RuntimeError(f"{var.name}: gradient contribution after its bucket's all-reduce was launched "
+                                   "(the model's graph changed between steps; set BDETR_DP_OVERLAP=0)")
+            return
+        if self._seen[k] < self._expected[k] or var.grad is not var.grad_buf:
+            return
+        for b in set(bs):
+            self._pending[b] -= 1
+            if self._pending[b] == 0 and not self._launched[b]:
+                self._launch(b)
+
+    def finish(self, flat: torch.Tensor) -> None:
+        """All-reduce whatever ``grad_ready`` did not launch, then make the current stream wait for every bucket."""
+        if self.world == 1:
+            return
+        if not getattr(self, "_active", False) or flat is not self._flat:
+            self.allreduce_(flat)
+            return
+        self._active = False
+        if self._expected is None:
+            self._expected = dict(self._seen)
+        for b in range(len(self._bounds)):
+            if not self._launched[b]:
+                self._launch(b)
+        for h in self._handles:
+            h.wait()
+        if flat.is_cuda:
+            torch.cuda.current_stream().wait_stream(self._comm_stream)
+        self._handles = []
 
     def broadcast_variables(self, variables: List[Variable]) -> None:
         """Replicas start from rank 0's values (weights AND moving statistics), like MirroredStrategy's mirrored
@@ -303,6 +417,10 @@ class Model(Layer):
             live = self.optimizer.flat_grad
             live.zero_()                         # ONE memset for all gradients (split-K GEMMs accumulate into zeros)
         ops.set_live_flat_grad(live)             # in-place gradient sinks are valid for slices of THIS buffer only
+        if self._dp is not None:
+            from .engine import side_stream
+            self._dp.begin_step(self.optimizer, torch.cuda.current_stream(), side_stream())
+            ops.set_grad_ready_hook(self._dp.grad_ready)
         tape = Tape()
         prev = K.set_launch_stream(torch.cuda.current_stream().cuda_stream)     # pin the launch stream for the step
         try:
@@ -313,6 +431,7 @@ class Model(Layer):
         finally:
             K.set_launch_stream(prev)
             ops.set_live_flat_grad(None)
+            ops.set_grad_ready_hook(None)
         join_side_stream()                                      # weight-gradient GEMMs ran on the side stream
         return y_pred
 
@@ -361,7 +480,7 @@ class Model(Layer):
                 K.flag_nonfinite(root)
             guard = K.overflow_flag()
         if self._dp is not None:
-            self._dp.allreduce_(self.optimizer.flat_grad)
+            self._dp.finish(self.optimizer.flat_grad)       # buckets not already in flight since the backward pass + join
             if guard is not None:
                 self._dp.any_(guard)
         self.optimizer.apply_gradients(skip_flag=guard)

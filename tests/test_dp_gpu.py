@@ -89,3 +89,53 @@ def test_two_replica_gradient_equivalence(cuda, tmp_path):
     outs = [p.communicate(timeout=600)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
     assert "DP_EQUIVALENCE_OK" in outs[0], outs[0][-2000:]
+
+
+_WORKER_CFG2 = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+import bench
+from boosted_detr_amd.engine import to_device
+args = type("A", (), dict(model="detr", fashionpedia=False, backbone="ResNet", image=640, image_w=0, layers=6, queries=100, learners=3, batch=32))()
+model = bench.build_model(args)
+host = bench.make_batch(32, 640, 640, 100, 82, seed=1234 + rank)
+batch = {"image": to_device(host["image"]), "category": to_device(host["category"], torch.int32), "attribute": to_device(host["attribute"], torch.int32),
+         "bbox": to_device(host["bbox"]), "num_objects": to_device(host["num_objects"], torch.int32)}
+model.distribute()
+losses = []
+for step in range(4):                 # step 0 builds, step 1 calibrates the bucket table, steps 2-3 overlap the all-reduce with backward
+    losses.append(model.logs_to_host(model.train_step(batch))["loss"])
+torch.cuda.synchronize()
+assert all(np.isfinite(l) for l in losses), losses
+assert model._dp._expected is not None and len(model._dp._bounds) >= 3
+# replicas hold identical weights after data-parallel steps on different shards
+digest = torch.stack([v.value.double().sum() for v in model.trainable_variables]).cpu()
+both = [torch.zeros_like(digest) for _ in range(world)]
+dist.all_gather(both, digest)
+assert torch.equal(both[0], both[1]), float((both[0] - both[1]).abs().max())
+peak = torch.cuda.max_memory_allocated() / 2**30
+reserved = torch.cuda.memory_reserved() / 2**30
+if rank == 0:
+    print("DP_CFG2_OK losses=%s peak_live_GiB=%.1f reserved_GiB=%.1f" % (" ".join("%.3f" % l for l in losses), peak, reserved))
+assert reserved < 2.0 * peak + 2.0, (reserved, peak)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_two_replicas_config2_batch32_overlapped_allreduce(cuda, tmp_path):
+    """BASELINE.json configs[3] per-rank work (32 images of 640x640, 6+6 layers) on two replicas sharing this box's GPU over
+    gloo: four data-parallel steps through the bucketed all-reduce that overlaps the backward pass; the replicas must end with
+    identical weights and the caching allocator must stay below 2x the live peak (no record_stream parking)."""
+    script = tmp_path / "dp_cfg2.py"
+    script.write_text(_WORKER_CFG2)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
+    assert "DP_CFG2_OK" in outs[0], outs[0][-2000:]
+    print(outs[0].strip().splitlines()[-1])

@@ -109,6 +109,36 @@ class V:  # broadcast path
 v = V(); v.value = torch.full((5,), float(dp.rank))
 dp.broadcast_variables([v])
 assert float(v.value.sum()) == 0.0
+# bucketed all-reduce launched from the backward pass (grad_ready) - buckets count from the END of the flat buffer
+class Opt: pass
+sizes = [1200, 800, 1500, 700, 796]
+offs = np.concatenate([[0], np.cumsum(sizes)])
+flat = torch.zeros(int(offs[-1]))
+vs = []
+for i, sz in enumerate(sizes):
+    q = V(); q.name = "v%d" % i; q.grad_buf = flat[int(offs[i]): int(offs[i]) + sz]; q.grad = None; q._grad_flat = flat
+    vs.append(q)
+opt = Opt(); opt.flat_grad = flat; opt.vars = vs
+dp2 = DataParallel(); dp2.BUCKET_ELEMS = 1000
+for step in range(4):
+    flat.zero_()
+    dp2.begin_step(opt, None, None)
+    early = 0
+    for i in reversed(range(len(vs))):                      # backward order: last variable first
+        q = vs[i]
+        q.grad_buf.copy_(torch.full((sizes[i],), float((dp2.rank + 1) * (i + 1) + step)))
+        q.grad = q.grad_buf
+        dp2.grad_ready(q)
+        if i == 2:                                          # a shared variable: second contribution lands later
+            q.grad_buf.add_(0.5)
+            dp2.grad_ready(q)
+        early = max(early, sum(dp2._launched)) if dp2._expected is not None and dp2._active else early
+    dp2.finish(flat)
+    for i, sz in enumerate(sizes):
+        want = sum((r + 1) * (i + 1) + step + (0.5 if i == 2 else 0.0) for r in range(dp2.world))
+        got = flat[int(offs[i]): int(offs[i]) + sz]
+        assert torch.all(got == want), (step, i, float(got[0]), want)
+    assert (early > 0) == (step >= 1), (step, early)        # step 0 calibrates the contribution counts, later steps overlap
 dist.barrier(); dist.destroy_process_group()
 print("rank", dp.rank, "ok")
 '''
