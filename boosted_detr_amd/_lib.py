@@ -73,6 +73,7 @@ SIGNATURES = {
     "bdetr_p16_pack": (I, [P, L, P, P, P, P]),
     "bdetr_p16_unpack": (I, [P, I, L, P, P]),
     "bdetr_p16_pack_conv_weights": (I, [P, I, I, I, I, P, P, P, P]),
+    "bdetr_p16_pack_conv_weights_multi": (I, [P, I, P, P]),
     "bdetr_p16_conv2d_fwd_stat_chunks": (I, [C.POINTER(ConvDesc)]),
     "bdetr_p16_conv2d_fwd": (I, [P, P, P, P, C.POINTER(ConvDesc), I, P, P, P]),
     "bdetr_p16_conv2d_bwd_data": (I, [P, P, P, C.POINTER(ConvDesc), I, P]),

@@ -103,20 +103,23 @@ __global__ void bn_frozen_kernel(const float* mm, const float* mv, int C, float 
     if (c < C) { mean[c] = mm[c]; rstd[c] = 1.0f / sqrtf(mv[c] + eps); }
 }
 
-// sum partials [nparts][C] -> out1[C], out2[C] (fp32 inputs, fp64 accumulation, fixed order)
+// sum partials [nparts][C] -> out1[C], out2[C] (fp32 inputs, fp64 accumulation, fixed order): 8 columns x 32 row
+// phases per block, so a thread walks nparts / 32 rows (the 32 columns x 8 phases shape took 12.9 us on 512 partial
+// rows: a 64-deep dependent load + add chain per thread)
 __global__ __launch_bounds__(256) void sum_partials2_kernel(const float* __restrict__ pa, const float* __restrict__ pb, int nparts, int C,
                                                             float* oa, float* ob) {
     __shared__ double s1[256], s2[256];
-    const int cx = threadIdx.x & 31, py = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cx;
+    const int cx = threadIdx.x & 7, py = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cx;
     double a = 0, b = 0;
-    if (c < C) for (int p = py; p < nparts; p += 8) { a += pa[(int64_t)p * C + c]; b += pb[(int64_t)p * C + c]; }
+    if (c < C) for (int p = py; p < nparts; p += 32) { a += pa[(int64_t)p * C + c]; b += pb[(int64_t)p * C + c]; }
     s1[threadIdx.x] = a; s2[threadIdx.x] = b;
     __syncthreads();
-    if (py == 0 && c < C) {
-        for (int k = 1; k < 8; ++k) { a += s1[cx + 32 * k]; b += s2[cx + 32 * k]; }
-        oa[c] = (float)a; ob[c] = (float)b;
+    for (int s = 16; s > 0; s >>= 1) {          // fixed-order tree over the 32 phases
+        if (py < s) { s1[threadIdx.x] += s1[threadIdx.x + 8 * s]; s2[threadIdx.x] += s2[threadIdx.x + 8 * s]; }
+        __syncthreads();
     }
+    if (py == 0 && c < C) { oa[c] = (float)s1[cx]; ob[c] = (float)s2[cx]; }
 }
 
 struct StatFn {
@@ -560,7 +563,7 @@ extern "C" int bdetr_bn_bwd(const float* dout, const float* out, const float* x,
     float* pa = ws; float* pb = ws + (int64_t)nch * C;
     BnBwdFn f{dout, out, x, mean, rstd, gamma, beta, C, relu};
     hipLaunchKernelGGL((colreduce2_kernel<BnBwdFn>), dim3(g.gx, nch), dim3(256), 0, st, f, rows, C, g.tx, rpc, pa, pb);
-    hipLaunchKernelGGL(sum_partials2_kernel, dim3((C + 31) / 32), dim3(256), 0, st, pa, pb, nch, C, dbeta, dgamma);
+    hipLaunchKernelGGL(sum_partials2_kernel, dim3((C + 7) / 8), dim3(256), 0, st, pa, pb, nch, C, dbeta, dgamma);
     int64_t n4 = rows * C / 4;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n4, 256, 2)), dim3(256), 0, st, dout, out, x, mean, rstd, gamma, beta, dgamma, dbeta,
                        relu, frozen, dx, dresidual, n4, C / 4, 1.0f / (float)rows);
@@ -592,7 +595,7 @@ extern "C" int bdetr_bn_bwd_p16(const float* dout, const void* out, int out_p16,
     float* pa = ws; float* pb = ws + (int64_t)nch * C;
     BnBwdFn f{dout, reinterpret_cast<const float*>(out), x, mean, rstd, gamma, beta, C, relu, out_p16};
     hipLaunchKernelGGL((colreduce2_kernel<BnBwdFn>), dim3(g.gx, nch), dim3(256), 0, st, f, rows, C, g.tx, rpc, pa, pb);
-    hipLaunchKernelGGL(sum_partials2_kernel, dim3((C + 31) / 32), dim3(256), 0, st, pa, pb, nch, C, dbeta, dgamma);
+    hipLaunchKernelGGL(sum_partials2_kernel, dim3((C + 7) / 8), dim3(256), 0, st, pa, pb, nch, C, dbeta, dgamma);
     const int64_t n4 = rows * C / 4;
     hipLaunchKernelGGL(bn_bwd_apply_p16_kernel, dim3(ew_grid(n4, 256, 2)), dim3(256), 0, st, dout, out, out_p16, x, mean, rstd, gamma, beta, dgamma, dbeta,
                        relu, frozen, dx32, dx_bf16, dresidual, n4, C / 4, 1.0f / (float)rows);
@@ -623,7 +626,7 @@ extern "C" int bdetr_add_dropout_layernorm_bwd(const float* dout, const float* x
     float* pg = ws; float* pb = ws + (int64_t)nch * D;
     hipLaunchKernelGGL(add_drop_ln_bwd_kernel, dim3(nch), dim3(256), 0, st, dout, x, y, gamma, mean, rstd, dx, dy, pg, pb,
                        rows, D, rpc, rate, seed, accumulate_dx);
-    hipLaunchKernelGGL(sum_partials2_kernel, dim3((D + 31) / 32), dim3(256), 0, st, pg, pb, nch, D, dgamma, dbeta);
+    hipLaunchKernelGGL(sum_partials2_kernel, dim3((D + 7) / 8), dim3(256), 0, st, pg, pb, nch, D, dgamma, dbeta);
     return bdetr_launch_status("add_dropout_layernorm_bwd");
 }
 

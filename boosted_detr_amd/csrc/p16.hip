@@ -44,7 +44,42 @@ __global__ __launch_bounds__(256) void p16_pack_wt_kernel(const float* __restric
     }
 }
 
+// every registered conv weight in ONE launch: row t of the table = {w, w_f16, wt_bf16, K, R, S, C} (int64 each);
+// blockIdx.y = tensor, the blocks of a row grid-stride over its 8-element groups (both copies)
+__global__ __launch_bounds__(256) void p16_pack_weights_multi_kernel(const int64_t* __restrict__ table, int* __restrict__ overflow_flag) {
+    const int64_t* row = table + (int64_t)blockIdx.y * 7;
+    const float* w = reinterpret_cast<const float*>(row[0]);
+    char* wf = reinterpret_cast<char*>(row[1]);
+    char* wt = reinterpret_cast<char*>(row[2]);
+    const int K = (int)row[3], R = (int)row[4], S = (int)row[5], C = (int)row[6];
+    const int64_t n8 = (int64_t)K * R * S * C / 8;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        if (wf != nullptr) {
+            const f32x4 a = reinterpret_cast<const f32x4*>(w)[2 * i], b = reinterpret_cast<const f32x4*>(w)[2 * i + 1];
+            const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+            p16_store8<true>(wf + i * 32, v);
+            if (overflow_flag && p16_f16_overflow(v)) *overflow_flag = 1;
+        }
+        if (wt != nullptr) {
+            const int c = (int)(i % C); int64_t t = i / C;
+            const int tap = (int)(t % (R * S)); const int kg = (int)(t / (R * S));
+            const int r = tap / S, s2 = tap - r * S;
+            const int src_tap = (R - 1 - r) * S + (S - 1 - s2);
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = w[((int64_t)(kg * 8 + e) * R * S + src_tap) * C + c];
+            p16_store8<false>(wt + (((int64_t)c * R * S + tap) * K + kg * 8) * 4, v);
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int bdetr_p16_pack_conv_weights_multi(const int64_t* table, int ntensors, int* overflow_flag, void* stream) {
+    BDETR_CHECK_ARG(table && ntensors > 0, "bdetr_p16_pack_conv_weights_multi: bad arguments");
+    hipLaunchKernelGGL(p16_pack_weights_multi_kernel, dim3(48, ntensors), dim3(256), 0, (hipStream_t)stream, table, overflow_flag);
+    return bdetr_launch_status("p16_pack_conv_weights_multi");
+}
 
 extern "C" int bdetr_p16_pack(const float* x, int64_t n, void* f16_out, void* bf16_out, int* overflow_flag, void* stream) {
     BDETR_CHECK_ARG(x && n > 0 && n % 8 == 0 && (f16_out || bf16_out), "bdetr_p16_pack: bad arguments (n %% 8 == 0 required)");

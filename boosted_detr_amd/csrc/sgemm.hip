@@ -530,8 +530,15 @@ extern "C" int bdetr_p16_conv2d_bwd_weight_splitk(const bdetr_conv_desc* d) {
     const int64_t Kd = (int64_t)d->R * d->S * d->C;
     const int t = wgrad_tile(d);
     const int64_t tiles = cdiv64(d->K, TILE_BM[t]) * cdiv64(Kd, TILE_BN[t]);
-    int64_t sk = cdiv64(3LL * num_cus(), tiles);
-    const int64_t maxsk = cdiv64(M, 8 * BK);       // keep >= 8 stages per split
+    static int want_x = 0, min_stages = 0;
+    if (want_x == 0) {
+        const char* e = getenv("BDETR_WGRAD_WANT"); want_x = e ? atoi(e) : 2;      // measured: 2 workgroups per CU (5.9 ms over the ResNet-50 layers) beats 1 (6.5), 3 (6.4), 4 (6.9): atomic bytes grow with the split
+        const char* f = getenv("BDETR_WGRAD_MINSTAGES"); min_stages = f ? atoi(f) : 8;
+        if (want_x < 1) want_x = 1;
+        if (min_stages < 1) min_stages = 1;
+    }
+    int64_t sk = cdiv64((int64_t)want_x * num_cus(), tiles);
+    const int64_t maxsk = cdiv64(M, (int64_t)min_stages * BK);       // keep >= min_stages K-steps per split
     if (sk > maxsk) sk = maxsk;
     if (sk < 1) sk = 1;
     if (sk > 512) sk = 512;

@@ -310,6 +310,12 @@ def bn_bwd_p16(dout, out, x2d, mean, rstd, gamma, relu, frozen, want_residual_gr
     return dxb, dx32, dgamma, dbeta, dres
 
 
+def p16_pack_conv_weights_multi(table: torch.Tensor) -> None:
+    """table: int64 [n,7] device tensor of {w, w_f16, wt_bf16, K, R, S, C} rows."""
+    _chk(table, dtype=torch.int64)
+    check(_lib.lib().bdetr_p16_pack_conv_weights_multi(_p(table), table.shape[0], _p(overflow_flag()), _stream()), "p16_pack_conv_weights_multi")
+
+
 def p16_conv2d_fwd(x_f16, w_f16, bias, g: ConvGeom, act: int = ACT_NONE, want_stats: bool = False):
     _chk(x_f16, w_f16, bias)
     L = _lib.lib()

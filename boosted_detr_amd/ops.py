@@ -170,18 +170,41 @@ def _packed_input(x: torch.Tensor, need_bf16: bool):
     return xf, xb
 
 
-def packed_weights(w: Variable, need_bwd: bool):
-    """(P16-f16 forward copy, P16-bf16 transposed tap-flipped copy | None) of a conv kernel, repacked when the
-    weights changed (optimizer step / assign)."""
-    c = getattr(w, "_p16", None)
-    if c is None or c[0] != WEIGHTS_VERSION[0]:
-        c = [WEIGHTS_VERSION[0], None, None]
-        w._p16 = c
-    if c[1] is None or (need_bwd and c[2] is None):
-        wf, wt = K.p16_pack_conv_weights(w.value, want_fwd=c[1] is None, want_bwd=need_bwd and c[2] is None)
-        c[1] = wf if c[1] is None else c[1]
-        c[2] = wt if wt is not None else c[2]
-    return c[1], c[2]
+class _PackedWeights:
+    """Both P16 copies of every conv kernel that takes the pre-split path, in persistent buffers, refreshed by ONE
+    multi-tensor launch the first time a copy is asked for after the weights changed (optimizer step / assign).
+    The table keeps the buffers of its rows alive; rows of variables that no longer exist are dropped whenever the
+    table is rebuilt (a new variable registers)."""
+
+    def __init__(self):
+        self.rows, self.table, self.version = [], None, -1       # rows: (weakref(var), value, wf, wt)
+
+    def get(self, w: Variable):
+        import weakref
+        c = getattr(w, "_p16", None)
+        if c is None or c[0].data_ptr() != w.value.data_ptr():
+            Kout, R, S, Cin = w.value.shape
+            c = (w.value, torch.empty_like(w.value), torch.empty((Cin, R, S, Kout), dtype=torch.float32, device=w.value.device))
+            w._p16 = c
+            self.rows = [r for r in self.rows if r[0]() is not None and r[0]() is not w]
+            self.rows.append((weakref.ref(w),) + c)
+            self.table, self.version = None, -1
+        if self.version != WEIGHTS_VERSION[0]:
+            if self.table is None:
+                import numpy as np
+                rows = np.array([[v.data_ptr(), wf.data_ptr(), wt.data_ptr(), *v.shape] for _, v, wf, wt in self.rows], np.int64)
+                self.table = torch.from_numpy(rows).to(w.value.device)
+            K.p16_pack_conv_weights_multi(self.table)
+            self.version = WEIGHTS_VERSION[0]
+        return c[1], c[2]
+
+
+_PACKED = _PackedWeights()
+
+
+def packed_weights(w: Variable, need_bwd: bool = True):
+    """(P16-f16 forward copy [K,R,S,C], P16-bf16 transposed tap-flipped copy [C,R,S,K]) of a conv kernel."""
+    return _PACKED.get(w)
 
 
 def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int, pad: int, relu: bool,

@@ -162,6 +162,9 @@ int bdetr_p16_unpack(const void* p, int is_f16, int64_t n, float* out, void* str
  * flipped taps, wt[c][r][s][k] = w[k][R-1-r][S-1-s][c] (backward-data B operand); either may be null */
 int bdetr_p16_pack_conv_weights(const float* w, int K, int R, int S, int C, void* w_f16, void* wt_bf16,
                                 int* overflow_flag, void* stream);
+/* the same for many weight tensors in one launch: `table` (device) holds ntensors rows of 7 int64
+ * {w, w_f16, wt_bf16, K, R, S, C}; null output pointers skip that copy */
+int bdetr_p16_pack_conv_weights_multi(const int64_t* table, int ntensors, int* overflow_flag, void* stream);
 /* y fp32 [N,OH,OW,K] = conv(x_f16 P16-f16 [N,H,W,C], w_f16) + bias, act, BatchNorm partial column sums as
  * bdetr_conv2d_fwd (stat_* sized with bdetr_p16_conv2d_fwd_stat_chunks rows) */
 int bdetr_p16_conv2d_fwd_stat_chunks(const bdetr_conv_desc* d);

@@ -8,8 +8,7 @@ a = A(); a.queries = 100; a.image = 640; a.layers = 6; a.batch = 16; a.model = '
 from boosted_detr_amd.engine import to_device
 m = bench.build_model(a)
 host = bench.make_batch(16, 640, 640, 100, 82, 1234)
-batch = {"image": to_device(host["image"]), "category": host["category"], "attribute": host["attribute"], "bbox": to_device(host["bbox"]), "num_objects": to_device(host["num_objects"], torch.int32)}
-c, h = m.Tokenization([host["category"], host["attribute"]]); m.Tokenization.call = lambda i, training=False: (c, h)
+batch = {"image": to_device(host["image"]), "category": to_device(host["category"], torch.int32), "attribute": to_device(host["attribute"], torch.int32), "bbox": to_device(host["bbox"]), "num_objects": to_device(host["num_objects"], torch.int32)}
 for _ in range(3): m.train_step(batch)
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU], with_stack=True) as prof:
