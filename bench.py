@@ -183,6 +183,7 @@ def main():
     ap.add_argument("--fashionpedia", action="store_true", help="46 categories / 294 attributes, attribute_weight 1.0")
     ap.add_argument("--backbone", default="ResNet", choices=["ResNet", "ResNet101"], help="configs[4]: ResNet101 (no reference counterpart)")
     ap.add_argument("--no-batch32", action="store_true", help="skip the secondary measurement at configs[3]'s per-GPU batch (32)")
+    ap.add_argument("--no-graph", action="store_true", help="enqueue every step from Python instead of replaying the captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -223,6 +224,7 @@ def main():
 
     if world > 1:
         model.distribute()
+    model.use_graph = not args.no_graph and world == 1      # N > 1: the collectives are issued per bucket from the backward pass (eager)
     def note(msg):
         if rank == 0:
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
@@ -259,6 +261,7 @@ def main():
         from boosted_detr_amd import engine as _engine
         side_was = _engine._SIDE["enabled"]
         _engine.set_side_stream_enabled(False)
+        graph_was, model.use_graph = model.use_graph, False          # per-launch hipEvents need eager launches
         L.bdetr_prof_enable(1 if rank == 0 else 0)
         t1 = time.perf_counter()
         for _ in range(args.steps):
@@ -266,6 +269,7 @@ def main():
         torch.cuda.synchronize()
         prof_wall = time.perf_counter() - t1
         _engine.set_side_stream_enabled(side_was)
+        model.use_graph = graph_was
     if want_roof and rank == 0:
         ms, n, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
         _lib.check(L.bdetr_prof_read(ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)), "prof_read")
@@ -341,7 +345,7 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": dtype_note(model), "arithmetic": arithmetic_note(model), "data": "synthetic",
             "config": {"workload": workload_name(args), "per_gpu_batch": args.batch, "global_batch": global_batch,
-                       "parallelism": f"dp{world}", "gflop_per_image_algorithmic": GFLOP_PER_IMAGE if is_config2(args) else None,
+                       "parallelism": f"dp{world}", "step_launch": "hipGraph replay" if model.use_graph else "eager", "gflop_per_image_algorithmic": GFLOP_PER_IMAGE if is_config2(args) else None,
                        "configs3": b32},
             "tflops_algorithmic": round(value * GFLOP_PER_IMAGE / 1e3, 2) if is_config2(args) else None,
             "final_loss": round(logs.get("loss", float("nan")), 4),

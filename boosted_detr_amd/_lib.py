@@ -98,9 +98,9 @@ SIGNATURES = {
     "bdetr_attention_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, P]),
     "bdetr_softmax_rows_fwd": (I, [P, P, L, I, F, P]),
     "bdetr_softmax_rows_bwd": (I, [P, P, P, L, I, F, P]),
-    "bdetr_add_dropout_layernorm_fwd": (I, [P, P, P, P, P, P, P, L, I, F, F, U64, P]),
+    "bdetr_add_dropout_layernorm_fwd": (I, [P, P, P, P, P, P, P, L, I, F, F, U64, P, P]),
     "bdetr_ln_bwd_chunks": (I, [L]),
-    "bdetr_add_dropout_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, L, I, F, U64, I, P]),
+    "bdetr_add_dropout_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, L, I, F, U64, P, I, P]),
     "bdetr_softmax_lastdim_fwd": (I, [P, P, L, I, P]),
     "bdetr_softmax_lastdim_bwd": (I, [P, P, P, L, I, P]),
     "bdetr_sigmoid_fwd": (I, [P, P, L, P]),

@@ -326,7 +326,9 @@ __device__ __forceinline__ float keep_scale(uint64_t seed, uint64_t idx, uint32_
 __global__ __launch_bounds__(256) void add_drop_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               float* __restrict__ out, float* __restrict__ mean_o, float* __restrict__ rstd_o,
-                                                              int64_t rows, int D, float eps, float rate, uint64_t seed) {
+                                                              int64_t rows, int D, float eps, float rate, uint64_t seed,
+                                                              const uint64_t* __restrict__ seed_base) {
+    if (seed_base != nullptr) seed ^= *seed_base * 0x100000001B3ull;       // per-step seed kept in HBM (graph replays)
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -377,7 +379,9 @@ __global__ __launch_bounds__(256) void add_drop_ln_fwd_kernel(const float* __res
 __global__ __launch_bounds__(256) void add_drop_ln_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ x, const float* __restrict__ y,
                                                               const float* __restrict__ gamma, const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                               float* __restrict__ dx, float* __restrict__ dy, float* __restrict__ pdg, float* __restrict__ pdb,
-                                                              int64_t rows, int D, int64_t rows_per_chunk, float rate, uint64_t seed, int accumulate_dx) {
+                                                              int64_t rows, int D, int64_t rows_per_chunk, float rate, uint64_t seed, int accumulate_dx,
+                                                              const uint64_t* __restrict__ seed_base) {
+    if (seed_base != nullptr) seed ^= *seed_base * 0x100000001B3ull;
     __shared__ f32x4 sg[4][64 * LN_MAXV], sb[4][64 * LN_MAXV];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int d4 = D / 4;
@@ -604,19 +608,19 @@ extern "C" int bdetr_bn_bwd_p16(const float* dout, const void* out, int out_p16,
 
 extern "C" int bdetr_add_dropout_layernorm_fwd(const float* x, const float* y, const float* gamma, const float* beta,
                                                float* out, float* mean, float* rstd, int64_t rows, int D,
-                                               float eps, float rate, uint64_t seed, void* stream) {
+                                               float eps, float rate, uint64_t seed, const uint64_t* seed_base, void* stream) {
     BDETR_CHECK_ARG(x && y && gamma && beta && out && mean && rstd && rows > 0, "bdetr_add_dropout_layernorm_fwd: null/empty argument");
     BDETR_CHECK_ARG(D % 4 == 0 && D > 0 && D <= 256 * LN_MAXV, "bdetr_add_dropout_layernorm_fwd: D=%d unsupported (multiple of 4, <= %d)", D, 256 * LN_MAXV);
     BDETR_CHECK_ARG(rate >= 0.f && rate < 1.f, "bdetr_add_dropout_layernorm_fwd: dropout rate must be in [0,1)");
     hipLaunchKernelGGL(add_drop_ln_fwd_kernel, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, (hipStream_t)stream,
-                       x, y, gamma, beta, out, mean, rstd, rows, D, eps, rate, seed);
+                       x, y, gamma, beta, out, mean, rstd, rows, D, eps, rate, seed, seed_base);
     return bdetr_launch_status("add_dropout_layernorm_fwd");
 }
 
 extern "C" int bdetr_add_dropout_layernorm_bwd(const float* dout, const float* x, const float* y, const float* gamma,
                                                const float* mean, const float* rstd, float* dx, float* dy,
                                                float* dgamma, float* dbeta, float* ws, int64_t rows, int D,
-                                               float rate, uint64_t seed, int accumulate_dx, void* stream) {
+                                               float rate, uint64_t seed, const uint64_t* seed_base, int accumulate_dx, void* stream) {
     BDETR_CHECK_ARG(dout && x && y && gamma && mean && rstd && dx && dy && dgamma && dbeta && ws && rows > 0,
                     "bdetr_add_dropout_layernorm_bwd: null/empty argument");
     BDETR_CHECK_ARG(D % 4 == 0 && D > 0 && D <= 256 * LN_MAXV, "bdetr_add_dropout_layernorm_bwd: D=%d unsupported", D);
@@ -625,7 +629,7 @@ extern "C" int bdetr_add_dropout_layernorm_bwd(const float* dout, const float* x
     int nch = (int)cdiv64(rows, rpc);
     float* pg = ws; float* pb = ws + (int64_t)nch * D;
     hipLaunchKernelGGL(add_drop_ln_bwd_kernel, dim3(nch), dim3(256), 0, st, dout, x, y, gamma, mean, rstd, dx, dy, pg, pb,
-                       rows, D, rpc, rate, seed, accumulate_dx);
+                       rows, D, rpc, rate, seed, accumulate_dx, seed_base);
     hipLaunchKernelGGL(sum_partials2_kernel, dim3((D + 7) / 8), dim3(256), 0, st, pg, pb, nch, D, dgamma, dbeta);
     return bdetr_launch_status("add_dropout_layernorm_bwd");
 }

@@ -561,17 +561,18 @@ def softmax_rows_bwd(p2d, dp2d, scale=1.0, out=None):
     return out
 
 
-def add_dropout_layernorm_fwd(x2d, y2d, gamma, beta, eps, rate=0.0, seed=0):
+def add_dropout_layernorm_fwd(x2d, y2d, gamma, beta, eps, rate=0.0, seed=0, seed_base=None):
+    """seed_base: device int64 [1] holding the per-step seed (folded into `seed` on the device)."""
     _chk(x2d, y2d, gamma, beta)
     rows, D = x2d.shape
     out = torch.empty_like(x2d)
     mean, rstd = empty(rows, like=x2d), empty(rows, like=x2d)
     check(_lib.lib().bdetr_add_dropout_layernorm_fwd(_p(x2d), _p(y2d), _p(gamma), _p(beta), _p(out), _p(mean), _p(rstd), rows, D, eps, rate,
-                                                     seed, _stream()), "add_dropout_layernorm_fwd")
+                                                     seed, _p(seed_base), _stream()), "add_dropout_layernorm_fwd")
     return out, mean, rstd
 
 
-def add_dropout_layernorm_bwd(dout, x2d, y2d, gamma, mean, rstd, rate=0.0, seed=0, dgamma=None, dbeta=None):
+def add_dropout_layernorm_bwd(dout, x2d, y2d, gamma, mean, rstd, rate=0.0, seed=0, dgamma=None, dbeta=None, seed_base=None):
     _chk(dout, x2d, y2d, gamma, mean, rstd, dgamma, dbeta)
     L = _lib.lib()
     rows, D = x2d.shape
@@ -580,7 +581,7 @@ def add_dropout_layernorm_bwd(dout, x2d, y2d, gamma, mean, rstd, rate=0.0, seed=
     dbeta = empty(D, like=x2d) if dbeta is None else dbeta
     ws = empty(2 * D * L.bdetr_ln_bwd_chunks(rows), like=x2d)
     check(L.bdetr_add_dropout_layernorm_bwd(_p(dout), _p(x2d), _p(y2d), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dy), _p(dgamma), _p(dbeta),
-                                            _p(ws), rows, D, rate, seed, 0, _stream()), "add_dropout_layernorm_bwd")
+                                            _p(ws), rows, D, rate, seed, _p(seed_base), 0, _stream()), "add_dropout_layernorm_bwd")
     return dx, dy, dgamma, dbeta
 
 

@@ -18,18 +18,29 @@ import torch
 from . import kernels as K
 from .engine import WEIGHTS_VERSION, Variable, current_tape, on_side_stream
 
+# Dropout masks are keyed by (per-step seed, dropout site, element index).  The per-step seed lives in HBM
+# (one int64 the host rewrites before every step), the site salt is a launch argument: a captured step graph then
+# draws fresh masks on every replay.
 _dropout_site = [0]
-_dropout_base_seed = [0x5EED]
+_dropout_seed_dev = [None]
 
 
-def set_dropout_seed(seed: int) -> None:
-    _dropout_base_seed[0] = int(seed) & 0xFFFFFFFFFFFF
+def dropout_seed_tensor() -> torch.Tensor:
+    if _dropout_seed_dev[0] is None:
+        _dropout_seed_dev[0] = torch.full((1,), 0x5EED, dtype=torch.int64, device="cuda")
+    return _dropout_seed_dev[0]
+
+
+def set_dropout_seed(seed: int, write: bool = True) -> None:
+    """Start a step: reset the site counter and (unless a graph replay already staged it) store the step's seed."""
+    if write:
+        dropout_seed_tensor().fill_(int(seed) & 0x7FFFFFFFFFFF)
     _dropout_site[0] = 0
 
 
 def _next_dropout_seed() -> int:
     _dropout_site[0] += 1
-    return (_dropout_base_seed[0] * 0x100000001B3 + _dropout_site[0] * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    return (_dropout_site[0] * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
 
 
 def _rec(outputs, inputs, fn):
@@ -548,13 +559,14 @@ def add_dropout_layernorm(x: torch.Tensor, y: torch.Tensor, gamma: Variable, bet
     r = rate if training else 0.0
     seed = _next_dropout_seed() if r > 0.0 else 0
     x2d, y2d = _2d(x), _2d(y)
-    out2d, mean, rstd = K.add_dropout_layernorm_fwd(x2d, y2d, gamma.value, beta.value, eps, r, seed)
+    base = dropout_seed_tensor() if r > 0.0 else None
+    out2d, mean, rstd = K.add_dropout_layernorm_fwd(x2d, y2d, gamma.value, beta.value, eps, r, seed, seed_base=base)
     out = out2d.view(x.shape)
 
     def backward(g_out):
         sg, sb = GradSink(gamma), GradSink(beta)
         dx, dy, _, _ = K.add_dropout_layernorm_bwd(_2d(g_out.contiguous()), x2d, y2d, gamma.value, mean, rstd, r, seed,
-                                                   dgamma=sg.buf, dbeta=sb.buf)
+                                                   dgamma=sg.buf, dbeta=sb.buf, seed_base=base)
         sg.commit()
         sb.commit()
         return _own(dx.view(x.shape)), _own(dy.view(y.shape))

@@ -122,9 +122,14 @@ class SGD:
                 gv.copy_(v.grad.view(gv.shape))          # D2D memcpy (plumbing): first step / shared-variable temporaries
             v.grad = gv
 
-    def apply_gradients(self, grad_scale: float = 1.0, skip_flag: Optional[torch.Tensor] = None) -> None:
-        """skip_flag: device int32; while it is non-zero the update is not applied (the step's range guard)."""
+    def stage_lr(self) -> None:
         self.d_lr.fill_(self.current_lr())
+
+    def apply_gradients(self, grad_scale: float = 1.0, skip_flag: Optional[torch.Tensor] = None, stage_lr: bool = True) -> None:
+        """skip_flag: device int32; while it is non-zero the update is not applied (the step's range guard).
+        stage_lr=False: the caller already wrote this iteration's learning rate to the device (graph replays)."""
+        if stage_lr:
+            self.stage_lr()
         st = torch.cuda.current_stream().cuda_stream
         _lib.check(_lib.lib().bdetr_sgd_nesterov_clipnorm(
             self.d_ptrs.data_ptr(), self.d_sizes.data_ptr(), len(self.vars), self.d_slab_tensor.data_ptr(),
@@ -370,6 +375,8 @@ class Model(Layer):
         self.guard_check_every = 50
         self.range_redos = 0
         self._guard_count = 0
+        self.use_graph = os.environ.get("BDETR_GRAPH", "0") == "1"      # capture train_step as a hipGraph (see _graph_step)
+        self._graphs, self._graph_warm = {}, {}
 
     # -- Keras bookkeeping -----------------------------------------------------------------
     def add_loss(self, loss) -> None:
@@ -404,12 +411,15 @@ class Model(Layer):
         return self
 
     # -- one step ----------------------------------------------------------------------------
-    def forward_backward(self, data: dict):
-        """forward + matcher + loss + backward.  Leaves gradients in Variable.grad."""
-        self._step_losses, self._loss_roots, self._step_metrics = [], [], {}
+    def _step_seed(self) -> int:
         # per-step, per-replica dropout masks: replicas draw independent masks (as under MirroredStrategy)
         rank = self._dp.rank if self._dp is not None else 0
-        ops.set_dropout_seed(0x5EED + self.steps_done + 0x9E3779B1 * rank)
+        return 0x5EED + self.steps_done + 0x9E3779B1 * rank
+
+    def forward_backward(self, data: dict, stage_seed: bool = True):
+        """forward + matcher + loss + backward.  Leaves gradients in Variable.grad."""
+        self._step_losses, self._loss_roots, self._step_metrics = [], [], {}
+        ops.set_dropout_seed(self._step_seed(), write=stage_seed)
         for v in self.variables:
             v.reset_grad()
         live = None
@@ -438,6 +448,67 @@ class Model(Layer):
     def _guarded(self) -> bool:
         return (self.train_gemm_precision or K.get_gemm_precision()) == "split"
 
+    # -- the step as a hipGraph ----------------------------------------------------------------------------
+    # ~1500 kernel launches, ~1300 allocator calls and the Python tape make up 20 ms of host work per step.  With
+    # ``use_graph`` the third step on a given input signature is captured (torch.cuda.graph: the caching allocator
+    # hands the capture a private pool, so every intermediate of the step lives at a fixed address) and later steps
+    # copy the batch into the captured input tensors, write the two per-step scalars (dropout seed, learning rate)
+    # to HBM and replay.  The reference's equivalent is tf.function / XLA (DETR_COCO.ipynb cell 3 enables the JIT).
+    def _graph_signature(self, data: dict):
+        if not self.use_graph or self._dp is not None or self.validate_matching:
+            return None
+        if not all(isinstance(v, torch.Tensor) and v.is_cuda for v in data.values()):
+            return None
+        return tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(data.items())) + (self.train_gemm_precision,)
+
+    def _device_step(self, data: dict, stage_scalars: bool) -> Dict[str, list]:
+        """Everything of a training step that runs on the device; no host synchronisation."""
+        self.forward_backward(data, stage_seed=stage_scalars)
+        tv = self.trainable_variables
+        self.optimizer.stage_gradients(tv)
+        guard = None
+        if self._guarded():
+            for root in self._loss_roots:
+                K.flag_nonfinite(root)
+            guard = K.overflow_flag()
+        if self._dp is not None:
+            self._dp.finish(self.optimizer.flat_grad)       # buckets not already in flight since the backward pass + join
+            if guard is not None:
+                self._dp.any_(guard)
+        self.optimizer.apply_gradients(skip_flag=guard, stage_lr=stage_scalars)
+        self.steps_done += 1
+        return self.step_logs()
+
+    def _graph_step(self, data: dict, sig) -> Optional[Dict[str, list]]:
+        entry = self._graphs.get(sig)
+        if entry is None:
+            n = self._graph_warm.get(sig, 0)
+            self._graph_warm[sig] = n + 1
+            if n < 2 or getattr(self.optimizer, "flat_grad", None) is None:
+                return None                                  # eager: build-by-first-call, allocator warm-up, flat buffers
+            static = {k: v.clone() for k, v in data.items()}
+            ops.set_dropout_seed(self._step_seed())          # the captured kernels read both scalars from HBM
+            self.optimizer.stage_lr()
+            keep = (self.steps_done, self.optimizer.iterations)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                logs = self._device_step(static, stage_scalars=False)
+            self.steps_done, self.optimizer.iterations = keep         # capturing is not a step
+            entry = (g, static, logs, (list(self._step_losses), list(self._loss_roots), dict(self._step_metrics)))
+            self._graphs[sig] = entry
+        g, static, logs, book = entry
+        for k, v in data.items():
+            if v is not static[k]:
+                static[k].copy_(v)
+        ops.set_dropout_seed(self._step_seed())
+        self.optimizer.stage_lr()
+        g.replay()
+        self._step_losses, self._loss_roots, self._step_metrics = list(book[0]), list(book[1]), dict(book[2])
+        self.steps_done += 1
+        self.optimizer.iterations += 1
+        bump_weights_version()
+        return logs
+
     def train_step(self, data: dict) -> Dict[str, torch.Tensor]:
         logs = self._train_step_once(data)
         if self._guarded() and self.guard_check_every:
@@ -459,6 +530,11 @@ class Model(Layer):
     def _train_step_once(self, data: dict) -> Dict[str, torch.Tensor]:
         if self.optimizer is None:
             raise RuntimeError("call compile(optimizer=...) before fit/train_step")
+        sig = self._graph_signature(data)
+        if sig is not None:
+            logs = self._graph_step(data, sig)
+            if logs is not None:
+                return logs
         if self._dp is not None and not getattr(self, "_dp_synced", True) and self.built_variables():
             self._dp.broadcast_variables(self.variables)
             self._dp_synced = True

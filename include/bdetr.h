@@ -278,11 +278,13 @@ int bdetr_attention_bwd(const float* q, const float* k, const float* v, const fl
  * K8  residual + dropout + LayerNormalization (transformers.py:135-137,178-180)
  *     h = x + dropout(y) ; out = gamma*(h-mean)*rstd + beta   (eps 1e-3, biased var)
  *     dropout: inverted, keep-prob 1-rate, counter-based RNG keyed by (seed, element index);
- *     rate==0 disables.  hbuf (optional) receives h for the backward pass.
+ *     rate==0 disables.  seed_base (device uint64*, may be null): a per-step value kept in HBM and folded
+ *     into `seed`, so that a captured hipGraph draws fresh masks on every replay (the host updates the word
+ *     between replays); forward and backward of one layer must be given the same pair.
  * ---------------------------------------------------------------------- */
 int bdetr_add_dropout_layernorm_fwd(const float* x, const float* y, const float* gamma, const float* beta,
                                     float* out, float* mean, float* rstd, int64_t rows, int D,
-                                    float eps, float rate, uint64_t seed, void* stream);
+                                    float eps, float rate, uint64_t seed, const uint64_t* seed_base, void* stream);
 /* given dout: dx (gradient to x, = dh), dy (gradient to y, = dh * dropout mask), dgamma, dbeta.
  * `out` is the forward output (h is recovered as (out-beta)/gamma is NOT used; xhat is
  * recomputed from x,y,mean,rstd).  ws: 2*D*bdetr_ln_bwd_chunks(rows) floats. */
@@ -290,7 +292,7 @@ int bdetr_ln_bwd_chunks(int64_t rows);
 int bdetr_add_dropout_layernorm_bwd(const float* dout, const float* x, const float* y, const float* gamma,
                                     const float* mean, const float* rstd, float* dx, float* dy,
                                     float* dgamma, float* dbeta, float* ws, int64_t rows, int D,
-                                    float rate, uint64_t seed, int accumulate_dx, void* stream);
+                                    float rate, uint64_t seed, const uint64_t* seed_base, int accumulate_dx, void* stream);
 
 /* ------------------------------------------------------------------------
  * K9  head activations (prediction_heads.py:44,60-62,111,127-129,180,197-199)

@@ -266,3 +266,34 @@ def test_range_guard_redoes_an_overflowing_step_on_the_fp32_forward(cuda):
         scale = np.abs(b[key]).max() + 1e-12
         assert np.abs(a[key] - b[key]).max() <= 1e-4 * scale, key      # weights and downstream moving statistics: one update, from the redo
     assert m.optimizer.iterations == 1 and m.steps_done == 1           # the guarded attempt applied nothing and is not counted
+
+
+def test_graph_replayed_steps_equal_eager_steps(cuda):
+    """Model.use_graph: the third step on an input signature is captured as a hipGraph and later steps replay it.  With
+    dropout on (masks keyed by a per-step seed kept in HBM) and a cosine learning-rate schedule (rate staged in HBM per
+    step), six replayed steps must track six eagerly enqueued ones: same losses, same weights (split-K atomics make any two
+    runs differ in the last bits, and a 2-image toy trajectory amplifies that - hence the loose late-step bound)."""
+    from boosted_detr_amd.engine import to_device
+    from boosted_detr_amd.training import SGD, CosineDecayRestarts
+    from oracle import detr_oracle as O
+    cfg, host = small_batch()
+    params = O.make_params(cfg, seed=1)
+    dev_batch = lambda b: {"image": to_device(b["image"]), "category": to_device(b["category"], torch.int32),
+                           "attribute": to_device(b["attribute"], torch.int32), "bbox": to_device(b["bbox"]),
+                           "num_objects": to_device(b["num_objects"], torch.int32)}
+    batches = [dev_batch(host), dev_batch(small_batch(seed=21)[1])]
+    runs = {}
+    for graph in (False, True):
+        m = small_model(dropout=0.1)
+        m.compile(optimizer=SGD(CosineDecayRestarts(1e-3, 10, m_mul=.95, alpha=.1), momentum=.9, nesterov=True, clipnorm=.1))
+        m.forward_backward(batches[0])
+        m.set_weights_dict(params)
+        m.use_graph = graph
+        losses = [m.logs_to_host(m.train_step(batches[i % 2]))["loss"] for i in range(8)]
+        assert (len(m._graphs) == 1) == graph and m.steps_done == 8 and m.optimizer.iterations == 8
+        runs[graph] = (losses, m.get_weights_dict())
+    le, lg = runs[False][0], runs[True][0]
+    assert all(np.isfinite(lg))
+    assert all(abs(a - b) <= 1e-4 * abs(a) for a, b in zip(le[:4], lg[:4])), (le, lg)      # first replayed steps: same numbers
+    assert all(abs(a - b) <= 5e-2 * abs(a) for a, b in zip(le, lg)), (le, lg)
+    assert lg[2] != lg[4]                                                                    # fresh masks / inputs per replay, not a frozen step
