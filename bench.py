@@ -183,7 +183,8 @@ def main():
     ap.add_argument("--fashionpedia", action="store_true", help="46 categories / 294 attributes, attribute_weight 1.0")
     ap.add_argument("--backbone", default="ResNet", choices=["ResNet", "ResNet101"], help="configs[4]: ResNet101 (no reference counterpart)")
     ap.add_argument("--no-batch32", action="store_true", help="skip the secondary measurement at configs[3]'s per-GPU batch (32)")
-    ap.add_argument("--no-graph", action="store_true", help="enqueue every step from Python instead of replaying the captured hipGraph")
+    ap.add_argument("--graph", action="store_true", help="replay the step as a captured hipGraph (Model.use_graph) instead of enqueuing it from "
+                    "Python: host-free steps, but measured slower than eager + side stream on ROCm 7.2 (profiles/README.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -224,7 +225,7 @@ def main():
 
     if world > 1:
         model.distribute()
-    model.use_graph = not args.no_graph and world == 1      # N > 1: the collectives are issued per bucket from the backward pass (eager)
+    model.use_graph = args.graph and world == 1             # N > 1: the collectives are issued per bucket from the backward pass (eager)
     def note(msg):
         if rank == 0:
             print(f"[bench] {msg}", file=sys.stderr, flush=True)

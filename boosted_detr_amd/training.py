@@ -454,6 +454,10 @@ class Model(Layer):
     # hands the capture a private pool, so every intermediate of the step lives at a fixed address) and later steps
     # copy the batch into the captured input tensors, write the two per-step scalars (dropout seed, learning rate)
     # to HBM and replay.  The reference's equivalent is tf.function / XLA (DETR_COCO.ipynb cell 3 enables the JIT).
+    # Measured on MI355X / ROCm 7.2 (config 2, batch 16): eager + side stream 477 images/s; graph of the single-stream
+    # step 447 (4 % faster than the same step enqueued eagerly, 429: no launch gaps); graph WITH the side-stream branch
+    # 256 (the ~110 main->side edges are expensive in hipGraph's executor).  The capture therefore keeps the
+    # weight-gradient GEMMs in stream order, and the mode is opt-in: it trades 6 % of throughput for a host-free step.
     def _graph_signature(self, data: dict):
         if not self.use_graph or self._dp is not None or self.validate_matching:
             return None
@@ -490,9 +494,15 @@ class Model(Layer):
             ops.set_dropout_seed(self._step_seed())          # the captured kernels read both scalars from HBM
             self.optimizer.stage_lr()
             keep = (self.steps_done, self.optimizer.iterations)
+            from .engine import _SIDE, set_side_stream_enabled
+            side_was = _SIDE["enabled"]
+            set_side_stream_enabled(False)                   # one chain: see the measurements above
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                logs = self._device_step(static, stage_scalars=False)
+            try:
+                with torch.cuda.graph(g):
+                    logs = self._device_step(static, stage_scalars=False)
+            finally:
+                set_side_stream_enabled(side_was)
             self.steps_done, self.optimizer.iterations = keep         # capturing is not a step
             entry = (g, static, logs, (list(self._step_losses), list(self._loss_roots), dict(self._step_metrics)))
             self._graphs[sig] = entry
