@@ -104,11 +104,13 @@ def hbm_traffic_per_launch():
     """HBM bytes per igemm launch from the PMC passes committed under profiles/ (rocprofv3 --pmc
     FETCH_SIZE and --pmc WRITE_SIZE in separate runs of this same command, with the gfx950 corrections
     of MI355X_MICROARCH.md: FETCH_SIZE x2, KB units).  None when the file is absent."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_igemm_hbm_traffic.json")) as f:
-            return round(json.load(f)["hbm_bytes_per_launch"])
-    except Exception:
-        return None
+    for name in ("r02_gemm_hbm_traffic.json", "r01_igemm_hbm_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return round(json.load(f)["hbm_bytes_per_launch"])
+        except Exception:
+            continue
+    return None
 
 
 def dtype_note(model) -> str:
@@ -182,6 +184,7 @@ def main():
     ap.add_argument("--learners", type=int, default=3)
     ap.add_argument("--fashionpedia", action="store_true", help="46 categories / 294 attributes, attribute_weight 1.0")
     ap.add_argument("--backbone", default="ResNet", choices=["ResNet", "ResNet101"], help="configs[4]: ResNet101 (no reference counterpart)")
+    ap.add_argument("--no-fp32-policy", action="store_true", help="skip the secondary measurement under the exact-fp32 arithmetic policy")
     ap.add_argument("--no-batch32", action="store_true", help="skip the secondary measurement at configs[3]'s per-GPU batch (32)")
     ap.add_argument("--graph", action="store_true", help="replay the step as a captured hipGraph (Model.use_graph) instead of enqueuing it from "
                     "Python: host-free steps, but measured slower than eager + side stream on ROCm 7.2 (profiles/README.md)")
@@ -328,6 +331,27 @@ def main():
         b32 = {"per_gpu_batch": 32, "global_batch": 32 * world, "steps": k32, "ms_per_step": round(e32 / k32 * 1e3, 3),
                "value": round(32 * world * k32 / e32, 2), "unit": "images/s"}
         del batch32
+    # The same step under the exact-fp32 policy (every conv/GEMM product on v_mfma_f32_32x32x2_f32, the reference's
+    # arithmetic): reported next to the headline so that the reference-precision throughput is driver-timed too.
+    fp32_line = None
+    if not args.no_fp32_policy and is_config2(args):
+        keep_policy, model.train_gemm_precision = model.train_gemm_precision, "fp32"
+        for _ in range(2):
+            model.train_step(batch)
+        barrier()
+        t3 = time.perf_counter()
+        kf = max(3, args.steps // 2)
+        for _ in range(kf):
+            model.train_step(batch)
+        barrier()
+        ef = time.perf_counter() - t3
+        model.train_gemm_precision = keep_policy
+        if dist is not None:
+            t = torch.tensor([ef], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ef = float(t.item())
+        fp32_line = {"value": round(args.batch * world * kf / ef, 2), "unit": "images/s", "steps": kf, "ms_per_step": round(ef / kf * 1e3, 3),
+                     "arithmetic": "every conv/GEMM product exact fp32 (v_mfma_f32_32x32x2_f32)"}
     if world > 1:
         barrier()
     if dist is not None:
@@ -350,6 +374,7 @@ def main():
                        "configs3": b32},
             "tflops_algorithmic": round(value * GFLOP_PER_IMAGE / 1e3, 2) if is_config2(args) else None,
             "final_loss": round(logs.get("loss", float("nan")), 4),
+            "value_fp32_policy": fp32_line,
             "roofline": roof,
             "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(args),
         }

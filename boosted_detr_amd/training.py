@@ -416,8 +416,9 @@ class Model(Layer):
         rank = self._dp.rank if self._dp is not None else 0
         return 0x5EED + self.steps_done + 0x9E3779B1 * rank
 
-    def forward_backward(self, data: dict, stage_seed: bool = True):
-        """forward + matcher + loss + backward.  Leaves gradients in Variable.grad."""
+    def forward_backward(self, data: dict, stage_seed: bool = True, keep_tape: bool = False):
+        """forward + matcher + loss + backward.  Leaves gradients in Variable.grad.
+        keep_tape: keep the recorded tape so that ``replay_backward`` can run the backward pass again."""
         self._step_losses, self._loss_roots, self._step_metrics = [], [], {}
         ops.set_dropout_seed(self._step_seed(), write=stage_seed)
         for v in self.variables:
@@ -438,6 +439,7 @@ class Model(Layer):
                 with recording(tape):
                     y_pred = self(data, training=True)
                 tape.backward({id(t): t for t in self._loss_roots})     # parameter gradients land in Variable.grad (ops.GradSink)
+            self._kept_tape = tape if keep_tape else None
         finally:
             K.set_launch_stream(prev)
             ops.set_live_flat_grad(None)
@@ -447,6 +449,29 @@ class Model(Layer):
 
     def _guarded(self) -> bool:
         return (self.train_gemm_precision or K.get_gemm_precision()) == "split"
+
+    def replay_backward(self, gemm_precision: str) -> None:
+        """Diagnostic: run the backward pass of the last ``forward_backward(..., keep_tape=True)`` again from the SAME
+        saved forward (same activations, same ReLU / dropout masks, same match) under another GEMM arithmetic policy.
+        Differences between two replays are then the arithmetic of the gradient products alone."""
+        tape = getattr(self, "_kept_tape", None)
+        if tape is None:
+            raise RuntimeError("replay_backward needs forward_backward(data, keep_tape=True) first")
+        for v in self.variables:
+            v.reset_grad()
+        live = None
+        if self.optimizer is not None and getattr(self.optimizer, "flat_grad", None) is not None:
+            live = self.optimizer.flat_grad
+            live.zero_()
+        ops.set_live_flat_grad(live)
+        prev = K.set_launch_stream(torch.cuda.current_stream().cuda_stream)
+        try:
+            with K.gemm_precision(gemm_precision):
+                tape.backward({id(t): t for t in self._loss_roots})
+        finally:
+            K.set_launch_stream(prev)
+            ops.set_live_flat_grad(None)
+        join_side_stream()
 
     # -- the step as a hipGraph ----------------------------------------------------------------------------
     # ~1500 kernel launches, ~1300 allocator calls and the Python tape make up 20 ms of host work per step.  With
