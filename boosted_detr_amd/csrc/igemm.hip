@@ -204,7 +204,12 @@ void igemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
     // XCD-aware tile order: blocks that are dispatched to the same XCD (blockIdx % 8) get
     // consecutive logical tiles, and tile_j is the fast index, so one XCD's L2 sees the same
     // A rows (the expensive im2col gather) from neighbouring workgroups.
-    const int wg = xcd_tile(blockIdx.x, g.tiles_i * g.tiles_j);
+    // split-K launches: XCD-aware order over tiles x slices (a slice's tiles share operand rows; see sgemm.hip)
+    const int nwg_ = g.tiles_i * g.tiles_j;
+    const bool sk_ = g.ngroups == 0 && g.splitk > 1;
+    const int lin_ = sk_ ? xcd_tile(blockIdx.z * nwg_ + blockIdx.x, nwg_ * gridDim.z) : xcd_tile(blockIdx.x, nwg_);
+    const int zz_ = sk_ ? lin_ / nwg_ : blockIdx.z;
+    const int wg = sk_ ? lin_ - zz_ * nwg_ : lin_;
     const int tile_i = wg / g.tiles_j, tile_j = wg - tile_i * g.tiles_j;
     const int i0 = tile_i * BM, j0 = tile_j * BN;
 
@@ -222,7 +227,7 @@ void igemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
         LA::regroup(opa, pa, g.I, A_RC);
         LB::regroup(opb, pb, -1, B_RC);
     } else if (g.splitk > 1) {
-        r_begin = blockIdx.z * g.r_chunk;
+        r_begin = zz_ * g.r_chunk;
         r_end = min(g.R, r_begin + g.r_chunk);
     } else {
         b0 = blockIdx.z / g.nb1; b1 = blockIdx.z - b0 * g.nb1;

@@ -176,12 +176,18 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
 
-    const int wg = xcd_tile(blockIdx.x, g.tiles_i * g.tiles_j);
+    // XCD-aware order over the WHOLE grid (tiles x split-K slices): workgroups are dealt round-robin to the 8 XCDs in
+    // flattened launch order, and the tiles of one split-K slice read the same operand rows (the 9 taps of a 3x3
+    // weight gradient, the row / column tiles of a 1x1 one).  Remapping the tiles of each slice alone spread a slice's
+    // handful of tiles over all 8 L2s (measured: the 3x3 weight gradients fetched 13 GB per step for 1.4 GB of operands).
+    const int nwg = g.tiles_i * g.tiles_j;
+    const int lin = xcd_tile(blockIdx.z * nwg + blockIdx.x, nwg * gridDim.z);
+    const int zz = lin / nwg, wg = lin - zz * nwg;
     const int tile_i = wg / g.tiles_j, tile_j = wg - tile_i * g.tiles_j;
     const int i0 = tile_i * BM, j0 = tile_j * BN;
 
     int r_begin = 0, r_end = g.R;
-    if (g.splitk > 1) { r_begin = blockIdx.z * g.r_chunk; r_end = min(g.R, r_begin + g.r_chunk); }
+    if (g.splitk > 1) { r_begin = zz * g.r_chunk; r_end = min(g.R, r_begin + g.r_chunk); }
 
     const __amdgpu_buffer_rsrc_t rsA = make_rsrc(opa.p);
     const __amdgpu_buffer_rsrc_t rsB = make_rsrc(opb.p);

@@ -222,3 +222,44 @@ def test_backward_arithmetic_in_isolation(config1):
     assert n > 100, n
     print(f"split-vs-fp32 backward from one forward: worst relative L2 {worst:.2e} over {n} tensors")
     model._kept_tape = None
+
+
+def test_resnet101_backbone_matches_oracle(cuda):
+    """BASELINE.json configs[4]'s backbone: the ResNet-101 stage list (3, 4, 23, 3) - not in the reference, same
+    Keras v1 block as its ResNet-50 - inside a 1 + 1 layer DETR at 128x128, against the oracle run with the same stages:
+    outputs within 1e-3, class ids and match indices bit-exact, loss within 1e-3, every gradient tensor by grad_report."""
+    from boosted_detr_amd import parameters, transformers
+    from boosted_detr_amd.backbone import RESNET101_STAGES
+    from boosted_detr_amd.model import DETR
+    from oracle import detr_oracle as O
+    cfg = O.Config(image_size=(128, 128), num_object_preds=12, num_categories=12, num_attributes=6, stages=RESNET101_STAGES)
+    batch = O.make_batch(cfg, 2, 6, seed=31, num_objects=[3, 5])
+    params = O.make_params(cfg, seed=5)
+    transformers.AttentionBlock.dropout_rate = 0.0
+    transformers.FeedForwardBlock.dropout_rate = 0.0
+    model = DETR(num_object_preds=12, image_size=(128, 128), num_encoder_blocks=1, num_encoder_heads=8, encoder_dim=256, num_decoder_blocks=1,
+                 num_decoder_heads=8, decoder_dim=256, num_panoptic_heads=1, panoptic_dim=32, vocab_dict=parameters.synthetic_vocab(10, 4),
+                 attribute_weight=1.0, backbone_name="ResNet101")
+    ren = lambda k: k.replace("EncoderBackbone/resnet50/", "EncoderBackbone/resnet101/")      # the oracle keeps one scope name for every stage list
+    model.forward_backward(batch)
+    assert sum(1 for v in model.variables if "conv4_block23_" in v.name) > 0
+    model.set_weights_dict({ren(k): v for k, v in params.items()})
+    y = model.forward_backward(batch)
+    torch.cuda.synchronize()
+    out, g32 = O.train_step_grads(cfg, params, batch, dtype=torch.float32)
+    _, g64 = O.train_step_grads(cfg, params, batch, dtype=torch.float64)
+    for got, want in zip(y, (out.cat_preds, out.attribute_preds, out.box_preds)):
+        assert rel_err(got.cpu().numpy(), want.detach().numpy()) < 1e-3
+    assert np.array_equal(y[0].cpu().numpy().argmax(-1), out.cat_preds.detach().numpy().argmax(-1))
+    match = model.loss_fn.last_match.cpu().numpy()
+    want = -np.ones_like(match)
+    for b, (r, c) in enumerate(out.loss.matches):
+        want[b, r] = c
+    assert np.array_equal(match, want)
+    logs = model.logs_to_host(model.step_logs())
+    ref = float(out.loss_vector.detach().double().mean())
+    assert abs(logs["loss"] - ref) <= 1e-3 * abs(ref)
+    rows = grad_report(model, {ren(k): v for k, v in g32.items()}, {ren(k): v for k, v in g64.items()})
+    assert len(rows) > 300
+    bad = [r for r in rows if r[1] > max(4.0 * r[3], 5e-3) or r[0] > max(4.0 * r[2], 5e-2)]
+    assert not bad, "\n".join(f"{n}: gpu {a:.2e}/{b:.2e} cpu32 {c:.2e}/{d:.2e}" for a, b, c, d, n in bad[:12])

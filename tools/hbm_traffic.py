@@ -2,9 +2,9 @@
 into HBM bytes per GEMM-family launch (igemm_kernel + sgemm_kernel), per step, and per kernel name, with the gfx950
 corrections of MI355X_MICROARCH.md (FETCH_SIZE counts 128-B requests at 64 B -> x2; both counters are in KB).
 
-usage: python tools/hbm_traffic.py <fetch_dir> <write_dir> <steps_in_trace> <out.json> [kernel_stats.csv of the same command]
-With the optional kernel-stats CSV (rocprofv3 --kernel-trace --stats of the same command and step count) every
-kernel also gets its average HBM rate = bytes / time."""
+usage: python tools/hbm_traffic.py <fetch_dir> <write_dir> <steps_in_trace> <out.json> [kernel_stats.csv <steps_in_stats_trace>]
+With the optional kernel-stats CSV (rocprofv3 --kernel-trace --stats of the same command) every kernel also gets its
+average HBM rate = bytes per step / time per step."""
 import csv, glob, json, os, re, sys
 
 
@@ -34,9 +34,10 @@ def main():
     wb = sum(v[1] for v in fam(write)) * 1024
     allb = sum(v[1] for v in fetch.values()) * 2 * 1024 + sum(v[1] for v in write.values()) * 1024
     times = {}
-    if len(sys.argv) > 5:
+    if len(sys.argv) > 6:
+        tsteps = float(sys.argv[6])
         for r in csv.DictReader(open(sys.argv[5])):
-            times[r["Name"]] = float(r["TotalDurationNs"])
+            times[r["Name"]] = float(r["TotalDurationNs"]) / tsteps * steps          # scaled to this trace's step count
     per_kernel = []
     for k in set(fetch) | set(write):
         f_ = fetch.get(k, [0, 0.0]); w_ = write.get(k, [0, 0.0])
