@@ -91,10 +91,8 @@ def test_config2_batch16_properties(cuda):
         assert v.grad is not None and bool(torch.isfinite(v.grad).all()), v.name
     y2 = [t.cpu().numpy() for t in model.forward_backward(host)]
     assert all(np.array_equal(a, b) for a, b in zip(y1, y2))           # deterministic forward (same dropout seed)
-    l0 = model.logs_to_host(model.train_step(host))["loss"]
-    for _ in range(3):
-        l1 = model.logs_to_host(model.train_step(host))["loss"]
-    assert l1 < l0, (l0, l1)                                           # the optimizer step descends
+    ls = [model.logs_to_host(model.train_step(host))["loss"] for _ in range(10)]
+    assert np.mean(ls[6:]) < np.mean(ls[:3]), ls                       # the optimizer descends (dropout noise: compare means, not single steps)
 
 
 def test_config3_boosted_fashionpedia_batch2_matches_oracle(cuda):
