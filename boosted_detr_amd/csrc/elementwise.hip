@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void sum_over_batch_kernel(const float* __rest
 // column sums of [rows][cols] (any cols), two deterministic levels: per-chunk partials, then a
 // fixed-order fp64 sum of the partials.  block = 64 columns x 4 row phases.
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int64_t rows, int cols, int64_t rows_per_chunk,
-                                                             float* __restrict__ part) {
+                                                             float* __restrict__ part, float* __restrict__ acc_out) {
     __shared__ float s[256];
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cx;
@@ -145,7 +145,11 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     if (c < cols) for (int64_t r = r0 + ry; r < r1; r += 4) a += x[r * cols + c];
     s[threadIdx.x] = a;
     __syncthreads();
-    if (ry == 0 && c < cols) part[(int64_t)blockIdx.y * cols + c] = s[cx] + s[cx + 64] + s[cx + 128] + s[cx + 192];
+    if (ry == 0 && c < cols) {
+        const float v = s[cx] + s[cx + 64] + s[cx + 128] + s[cx + 192];
+        if (acc_out != nullptr) atomicAdd(acc_out + c, v);
+        else part[(int64_t)blockIdx.y * cols + c] = v;
+    }
 }
 // 32 columns x 8 part-phases per block, fp64, fixed order
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int nparts, int cols, float* __restrict__ out) {
@@ -264,12 +268,22 @@ static int64_t colsum_rows_per_chunk(int64_t rows, int cols) {
     if (rpc < 32) rpc = 32;
     return rpc;
 }
+// out[c] += sum over rows of x[.][c], one launch: every block reduces its row chunk in LDS and adds the 64 column sums with
+// float atomics (out must hold zeros or the running sum: the flat gradient buffer is zero-filled once per step)
+extern "C" int bdetr_colsum_accumulate(const float* x, int64_t rows, int cols, float* out, void* stream) {
+    BDETR_CHECK_ARG(x && out && rows > 0 && cols > 0, "bdetr_colsum_accumulate: bad arguments");
+    int64_t rpc = colsum_rows_per_chunk(rows, cols);
+    int nch = (int)cdiv64(rows, rpc);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 63) / 64, nch), dim3(256), 0, (hipStream_t)stream, x, rows, cols, rpc, (float*)nullptr, out);
+    return bdetr_launch_status("colsum_accumulate");
+}
+
 extern "C" int bdetr_colsum_chunks(int64_t rows) { return (int)cdiv64(rows, 32); }   // upper bound for any cols
 extern "C" int bdetr_colsum(const float* x, int64_t rows, int cols, float* out, float* ws, void* stream) {
     BDETR_CHECK_ARG(x && out && ws && rows > 0 && cols > 0, "bdetr_colsum: bad arguments");
     int64_t rpc = colsum_rows_per_chunk(rows, cols);
     int nch = (int)cdiv64(rows, rpc);
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 63) / 64, nch), dim3(256), 0, (hipStream_t)stream, x, rows, cols, rpc, ws);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 63) / 64, nch), dim3(256), 0, (hipStream_t)stream, x, rows, cols, rpc, ws, (float*)nullptr);
     hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 31) / 32), dim3(256), 0, (hipStream_t)stream, ws, nch, cols, out);
     return bdetr_launch_status("colsum");
 }

@@ -46,25 +46,22 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
     return __builtin_amdgcn_make_buffer_rsrc(q, 0, (int)NUM_RECORDS, 0x00020000);
 }
 
-// exact unsigned division by an invariant divisor d (1 <= d < 2^31) of n < 2^31: q = umulhi(n, mul) >> sh with
-// mul = floor(2^(32+sh) / d) + 1, sh = floor(log2 d); powers of two carry mul = 0 (plain shift).
-struct FastDiv { unsigned mul, sh; };
-inline FastDiv make_fastdiv(unsigned d) {
-    FastDiv f; unsigned s = 0; while ((2u << s) <= d) ++s;
-    f.sh = s;
-    f.mul = ((1u << s) == d) ? 0u : (unsigned)((((unsigned long long)1 << (32 + s)) / d) + 1);
-    return f;
-}
-__device__ __forceinline__ unsigned fdiv(unsigned n, FastDiv f) { return f.mul ? (__umulhi(n, f.mul) >> f.sh) : (n >> f.sh); }
-
 // ----------------------------------------------------------------------------------------
 // operands
 // ----------------------------------------------------------------------------------------
 // dense P16 matrix: RR: rows = x (I or J), cols = r.   XX: rows = r, cols = x.
 struct PDense { const void* p; unsigned ld; int rows, cols; };
-// im2col view of an NHWC P16 tensor: rows = output pixels (N*OH*OW), cols = (tap, channel) = R*S*C
-struct PPatch { const void* p; int N, H, W, C, OH, OW, R, S, stride, pad; int rows, cols; FastDiv dOW, dOHW; };
+// im2col view of an NHWC P16 tensor: rows = output pixels (N*OH*OW), cols = (tap, channel) = R*S*C.
+// The k* fields are the byte increments of the XX loader's running pixel offset (host-computed, wrapping uint32).
+struct PPatch {
+    const void* p; int N, H, W, C, OH, OW, R, S, stride, pad; int rows, cols;
+    int d_ow, d_oh;                   // BK = d_oh * OW + d_ow: how far one K-step moves (oh, ow)
+    unsigned k_step, k_wrap_ow, k_wrap_oh;
+};
 
+// All byte offsets are uint32 with wrapping arithmetic: operands span < 4 GB, intermediate sums of a padding pixel
+// may "underflow" but are only used when the bounds test passed.
+//
 // ---- RR: the reduction index is the contiguous one; a lane loads 16 bytes = 8 r of one half of ONE row ----
 struct RRDense {
     using Op = PDense;
@@ -82,59 +79,73 @@ struct RRDense {
 struct RRPatch {
     using Op = PPatch;
     using Col = int;
-    struct Row { int nbase, ih0, iw0; bool ok; };
-    struct Step { int tr, ts, c0; };                          // tap (row, col) and first channel of the K-step (C % 32 == 0)
+    // base = byte offset of the row's tap-(0,0) input pixel; the K-step's tap / channel offset is uniform (Step), so an
+    // address is base + tapoff + 16 q: no per-load multiplies
+    struct Row { unsigned base; int ih0, iw0; bool ok; };
+    struct Step { int tr, ts, c0; unsigned tapoff; };         // tap (row, col), first channel of the K-step (C % 32 == 0), their byte offset
     static __device__ __forceinline__ Row row(const Op& op, int r, int lim) {
         Row c; c.ok = r < lim;
         const int ohw = op.OH * op.OW;
         const int n = r / ohw, rem = r - n * ohw, oh = rem / op.OW, ow = rem - oh * op.OW;
-        c.nbase = n * op.H * op.W; c.ih0 = oh * op.stride - op.pad; c.iw0 = ow * op.stride - op.pad;
+        c.ih0 = oh * op.stride - op.pad; c.iw0 = ow * op.stride - op.pad;
+        c.base = ((unsigned)(n * op.H * op.W) + (unsigned)(c.ih0 * op.W + c.iw0)) * (unsigned)op.C * 4u;
         return c;
     }
+    static __device__ __forceinline__ unsigned tap_bytes(const Op& op, const Step& s) { return ((unsigned)(s.tr * op.W + s.ts) * (unsigned)op.C + (unsigned)s.c0) * 4u; }
     static __device__ __forceinline__ Step step_init(const Op& op, int r0) {
-        Step s; const int tap = r0 / op.C; s.c0 = r0 - tap * op.C; s.tr = tap / op.S; s.ts = tap - s.tr * op.S; return s;
+        Step s; const int tap = r0 / op.C; s.c0 = r0 - tap * op.C; s.tr = tap / op.S; s.ts = tap - s.tr * op.S; s.tapoff = tap_bytes(op, s); return s;
     }
     static __device__ __forceinline__ void step_next(const Op& op, Step& s) {
-        s.c0 += BK;
-        if (s.c0 >= op.C) { s.c0 = 0; if (++s.ts == op.S) { s.ts = 0; ++s.tr; } }
+        s.c0 += BK; s.tapoff += BK * 4u;
+        if (s.c0 >= op.C) { s.c0 = 0; if (++s.ts == op.S) { s.ts = 0; ++s.tr; } s.tapoff = tap_bytes(op, s); }
     }
     static __device__ __forceinline__ unsigned voff(const Op& op, const Row& c, const Step& s, int r0, int q, int r_lim) {
         const int ih = c.ih0 + s.tr, iw = c.iw0 + s.ts;
         const bool ok = c.ok && r0 + 8 * (q >> 1) < r_lim && (unsigned)ih < (unsigned)op.H && (unsigned)iw < (unsigned)op.W;
-        return ok ? ((unsigned)(c.nbase + ih * op.W + iw) * (unsigned)op.C + (unsigned)s.c0) * 4u + 16u * (unsigned)q : OOB;
+        return ok ? c.base + s.tapoff + 16u * (unsigned)q : OOB;
     }
 };
 
-// ---- XX: the reduction index is the strided one; a lane loads 16 bytes = 8 x-columns of one half of ONE r-row ----
+// ---- XX: the reduction index is the strided one; a lane loads 16 bytes = 8 x-columns of one half of ONE r-row.
+// A load's state (Col) is advanced by BK rows per K-step with adds only.
 struct XXDense {
     using Op = PDense;
     using Row = int; using Step = int;                        // (RR-mode state: unused)
-    struct Col { unsigned off; bool ok; };                    // per lane: byte offset of its chunk inside a row
-    static __device__ __forceinline__ Col col(const Op& op, int x0, int slot, int x_lim) {
-        Col c; c.ok = x0 + 8 * (slot >> 1) < x_lim; c.off = (unsigned)x0 * 4u + 16u * (unsigned)slot; return c;
+    struct Col { unsigned off; int r; bool ok; };             // running byte offset of (row r, the lane's chunk)
+    static __device__ __forceinline__ Col col(const Op& op, int x0, int slot, int x_lim, int r_first) {
+        Col c; c.ok = x0 + 8 * (slot >> 1) < x_lim; c.r = r_first;
+        c.off = (unsigned)r_first * op.ld * 4u + (unsigned)x0 * 4u + 16u * (unsigned)slot; return c;
     }
-    static __device__ __forceinline__ unsigned voff(const Op& op, const Col& c, int r, int r_lim) {
-        return (c.ok && r < r_lim) ? (unsigned)r * op.ld * 4u + c.off : OOB;
-    }
+    static __device__ __forceinline__ unsigned voff(const Op&, const Col& c, int r_lim) { return (c.ok && c.r < r_lim) ? c.off : OOB; }
+    static __device__ __forceinline__ void advance(const Op& op, Col& c) { c.r += BK; c.off += (unsigned)BK * op.ld * 4u; }
 };
 struct XXPatch {
     using Op = PPatch;
     using Row = int; using Step = int;
-    struct Col { int tr, ts; unsigned off; bool ok; };        // tap of the lane's 8 columns, channel byte offset inside the pixel
-    static __device__ __forceinline__ Col col(const Op& op, int x0, int slot, int x_lim) {
+    // (oh, ow) of the load's output pixel, (ih, iw) of the input pixel its tap reads, and the running byte offset of
+    // that input pixel's channel chunk
+    struct Col { int r, oh, ow, ih, iw; unsigned off; bool ok; };
+    static __device__ __forceinline__ Col col(const Op& op, int x0, int slot, int x_lim, int r_first) {
         Col c; const int x = x0 + 8 * (slot >> 1);
-        c.ok = x < x_lim;
+        c.ok = x < x_lim; c.r = r_first;
         const int tap = x / op.C, ch = x - tap * op.C;
-        c.tr = tap / op.S; c.ts = tap - c.tr * op.S;
-        c.off = (unsigned)ch * 4u + 16u * (unsigned)(slot & 1);
+        const int tr = tap / op.S, ts = tap - tr * op.S;
+        const int ohw = op.OH * op.OW;
+        const int n = r_first / ohw, rem = r_first - n * ohw;
+        c.oh = rem / op.OW; c.ow = rem - c.oh * op.OW;
+        c.ih = c.oh * op.stride - op.pad + tr; c.iw = c.ow * op.stride - op.pad + ts;
+        c.off = ((unsigned)(n * op.H * op.W) + (unsigned)(c.ih * op.W + c.iw)) * (unsigned)op.C * 4u + (unsigned)ch * 4u + 16u * (unsigned)(slot & 1);
         return c;
     }
-    static __device__ __forceinline__ unsigned voff(const Op& op, const Col& c, int r, int r_lim) {
-        const unsigned n = fdiv((unsigned)r, op.dOHW), rem = (unsigned)r - n * (unsigned)(op.OH * op.OW);
-        const unsigned oh = fdiv(rem, op.dOW), ow = rem - oh * (unsigned)op.OW;
-        const int ih = (int)oh * op.stride - op.pad + c.tr, iw = (int)ow * op.stride - op.pad + c.ts;
-        const bool ok = c.ok && r < r_lim && (unsigned)ih < (unsigned)op.H && (unsigned)iw < (unsigned)op.W;
-        return ok ? ((n * (unsigned)op.H + (unsigned)ih) * (unsigned)op.W + (unsigned)iw) * (unsigned)op.C * 4u + c.off : OOB;
+    static __device__ __forceinline__ unsigned voff(const Op& op, const Col& c, int r_lim) {
+        const bool ok = c.ok && c.r < r_lim && (unsigned)c.ih < (unsigned)op.H && (unsigned)c.iw < (unsigned)op.W;
+        return ok ? c.off : OOB;
+    }
+    static __device__ __forceinline__ void advance(const Op& op, Col& c) {
+        c.r += BK;
+        c.ow += op.d_ow; c.oh += op.d_oh; c.iw += op.d_ow * op.stride; c.ih += op.d_oh * op.stride; c.off += op.k_step;
+        if (c.ow >= op.OW) { c.ow -= op.OW; c.oh += 1; c.iw -= op.OW * op.stride; c.ih += op.stride; c.off += op.k_wrap_ow; }
+        while (c.oh >= op.OH) { c.oh -= op.OH; c.ih -= op.OH * op.stride; c.off += op.k_wrap_oh; }      // next image (several on maps smaller than a K-step)
     }
 };
 
@@ -215,13 +226,13 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
         for (int t = 0; t < NIA; ++t) {
             const int r = (t * NW + wave) * (64 / SA) + lane / SA;
             rrA[t] = r;
-            colA[t] = LA::col(opa, i0, (lane % SA) ^ xx_swz(r), opa.cols);
+            colA[t] = LA::col(opa, i0, (lane % SA) ^ xx_swz(r), opa.cols, r_begin + r);
         }
 #pragma unroll
         for (int t = 0; t < NIB; ++t) {
             const int r = (t * NW + wave) * (64 / SB) + lane / SB;
             rrB[t] = r;
-            colB[t] = LB::col(opb, j0, (lane % SB) ^ xx_swz(r), opb.cols);
+            colB[t] = LB::col(opb, j0, (lane % SB) ^ xx_swz(r), opb.cols, r_begin + r);
         }
     }
     // RR: per-K-step uniform state of the patch loaders (tap, first channel)
@@ -236,13 +247,13 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
             constexpr int t = l;
             unsigned vo;
             if constexpr (!XX) vo = LA::voff(opa, rowA[t], stA, r0, qA[t], min(r_end, opa.cols));
-            else               vo = LA::voff(opa, colA[t], r0 + rrA[t], min(r_end, opa.rows));
+            else               vo = LA::voff(opa, colA[t], min(r_end, opa.rows));
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(sa + (t * NW + wave) * 1024), 16, (int)vo, 0, 0, 0);
         } else {
             constexpr int t = l - NIA;
             unsigned vo;
             if constexpr (!XX) vo = LB::voff(opb, rowB[t], stB, r0, qB[t], min(r_end, opb.cols));
-            else               vo = LB::voff(opb, colB[t], r0 + rrB[t], min(r_end, opb.rows));
+            else               vo = LB::voff(opb, colB[t], min(r_end, opb.rows));
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void*)(sa + A_BYTES + (t * NW + wave) * 1024), 16, (int)vo, 0, 0, 0);
         }
     };
@@ -250,6 +261,12 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
     auto issue_all = [&](int buf, int r0) {
         [&]<int... L>(std::integer_sequence<int, L...>) { (issue_one(buf, r0, std::integral_constant<int, L>{}), ...); }(std::make_integer_sequence<int, NLOAD>{});
         if constexpr (!XX) { LA::step_next(opa, stA); LB::step_next(opb, stB); }
+        else {
+#pragma unroll
+            for (int t = 0; t < NIA; ++t) LA::advance(opa, colA[t]);
+#pragma unroll
+            for (int t = 0; t < NIB; ++t) LB::advance(opb, colB[t]);
+        }
     };
 
     // ---------------- accumulators ----------------
@@ -443,7 +460,11 @@ int check_conv(const bdetr_conv_desc* d, const char* who) {
 }
 
 PPatch make_patch(const void* p, int N, int H, int W, int C, int OH, int OW, int R, int S, int stride, int pad, int rows, int cols) {
-    PPatch o{p, N, H, W, C, OH, OW, R, S, stride, pad, rows, cols, make_fastdiv((unsigned)OW), make_fastdiv((unsigned)(OH * OW))};
+    PPatch o{p, N, H, W, C, OH, OW, R, S, stride, pad, rows, cols, BK % OW, BK / OW, 0u, 0u, 0u};
+    const unsigned c4 = (unsigned)C * 4u;
+    o.k_step = (unsigned)(o.d_ow * stride + o.d_oh * stride * W) * c4;
+    o.k_wrap_ow = (unsigned)(stride * W - OW * stride) * c4;                  // ow -= OW, oh += 1   (wrapping uint32)
+    o.k_wrap_oh = (unsigned)(H * W - OH * stride * W) * c4;                    // oh -= OH, next image
     return o;
 }
 bool is_1x1_dense(const bdetr_conv_desc* d) { return d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0; }
@@ -543,7 +564,9 @@ extern "C" int bdetr_p16_conv2d_bwd_weight_splitk(const bdetr_conv_desc* d) {
         if (want_x < 1) want_x = 1;
         if (min_stages < 1) min_stages = 1;
     }
-    int64_t sk = cdiv64((int64_t)want_x * num_cus(), tiles);
+    // floor, not ceil: all tiles x slices must fit the want_x * CUs resident slots at once - one workgroup more than
+    // that runs alone in a second round and doubles the launch's duration
+    int64_t sk = ((int64_t)want_x * num_cus()) / tiles;
     const int64_t maxsk = cdiv64(M, (int64_t)min_stages * BK);       // keep >= min_stages K-steps per split
     if (sk > maxsk) sk = maxsk;
     if (sk < 1) sk = 1;

@@ -416,7 +416,7 @@ def linear_bwd_data(dy2d, w, dx=None, accumulate=False):
 def _auto_splitk(I, J, R) -> int:
     cus = _lib.lib().bdetr_device_cus()
     tiles = max(1, ((I + 63) // 64) * ((J + 63) // 64))
-    sk = max(1, min((2 * cus + tiles - 1) // tiles, R // 128))
+    sk = max(1, min((2 * cus) // tiles, R // 128))      # floor: tiles x slices must not spill into a second round of workgroups
     return sk
 
 
@@ -433,10 +433,15 @@ def linear_bwd_weight(dy2d, x2d, dw=None, prezeroed: bool = False):
     return gemm_raw(O, K, M, dy2d, O, False, x2d, K, False, dw, K, splitk=sk, grad=True)
 
 
-def colsum(x2d, out=None):
+def colsum(x2d, out=None, prezeroed=False):
+    """Column sums.  prezeroed: `out` already holds zeros (a slice of the step's zero-filled flat gradient buffer) - one
+    launch that adds with float atomics instead of the two-kernel deterministic reduction."""
     _chk(x2d, out)
     L = _lib.lib()
     rows, cols = x2d.shape
+    if prezeroed and out is not None:
+        check(L.bdetr_colsum_accumulate(_p(x2d), rows, cols, _p(out), _stream()), "colsum_accumulate")
+        return out
     if out is None:
         out = empty(cols, like=x2d)
     ws = empty(L.bdetr_colsum_chunks(rows) * cols, like=x2d)

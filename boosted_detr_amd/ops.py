@@ -308,7 +308,7 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
                         if s.mode != "direct":
                             K.zero_(s.buf)
                     else:
-                        K.colsum(dy, out=s.buf)
+                        K.colsum(dy, out=s.buf, prezeroed=s.mode == "direct")
                     s.commit()
         dx = None
         if x_needs_grad:
@@ -349,7 +349,7 @@ def conv_act(x: torch.Tensor, w: Variable, b: Variable, stride: int, pad: int, a
                     s.commit()
                 if b.needs_grad:
                     s = GradSink(b)
-                    K.colsum(_2d(dpre), out=s.buf)
+                    K.colsum(_2d(dpre), out=s.buf, prezeroed=s.mode == "direct")
                     s.commit()
         return (_own(K.conv2d_bwd_data(dpre, w.value, g)),)
 
@@ -402,7 +402,7 @@ def dense(x: torch.Tensor, w: Variable, b: Variable, act: int = K.ACT_NONE) -> t
                     s.commit()
                 if b.needs_grad:
                     s = GradSink(b)
-                    K.colsum(g2d, out=s.buf)
+                    K.colsum(g2d, out=s.buf, prezeroed=s.mode == "direct")
                     s.commit()
         return (_own(K.linear_bwd_data(g2d, w.value).view(x.shape)),)
 
@@ -432,7 +432,7 @@ def dense_group(xs, ws, bs):
                         s.commit()
                     if b.needs_grad:
                         s = GradSink(b)
-                        K.colsum(g, out=s.buf)
+                        K.colsum(g, out=s.buf, prezeroed=s.mode == "direct")
                         s.commit()
         dxs = K.linear_bwd_data_group(g2, [w.value for w in ws])
         return tuple(_own(dx.view(x.shape)) for dx, x in zip(dxs, xs))

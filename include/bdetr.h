@@ -205,6 +205,9 @@ int bdetr_gemm_grouped(const bdetr_gemm_desc* g, int n, void* stream);
  * Deterministic two-level reduction; ws: cols * bdetr_colsum_chunks(rows) floats. */
 int bdetr_colsum_chunks(int64_t rows);
 int bdetr_colsum(const float* x, int64_t rows, int cols, float* out, float* ws, void* stream);
+/* the same sum ADDED into out with float atomics in one launch (no workspace): out must hold zeros or the running
+ * sum - the host's flat gradient buffer is zero-filled once per step */
+int bdetr_colsum_accumulate(const float* x, int64_t rows, int cols, float* out, void* stream);
 
 /* ------------------------------------------------------------------------
  * K3  BatchNormalization, training mode (keras BN inside ResNet-50, backbone.py:79-80,

@@ -51,6 +51,9 @@ def test_linear_bwd(cuda, M, K, O):
     close(dw, dy.double().T @ x.double())
     db = k.colsum(dev(dy))
     close(db, dy.double().sum(0))
+    acc = torch.zeros(O).cuda()
+    k.colsum(dev(dy), out=acc, prezeroed=True)          # one-launch form: float atomics into a zero-filled gradient slot
+    close(acc, dy.double().sum(0), rtol=1e-5)
 
 
 def test_gemm_batched_attention_shapes(cuda):
