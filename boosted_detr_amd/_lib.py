@@ -102,6 +102,10 @@ SIGNATURES = {
     "bdetr_add_dropout_layernorm_fwd": (I, [P, P, P, P, P, P, P, L, I, F, F, U64, P, P]),
     "bdetr_ln_bwd_chunks": (I, [L]),
     "bdetr_add_dropout_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, L, I, F, U64, P, I, P]),
+    "bdetr_resize_bilinear_nhwc": (I, [P, I, I, I, I, P, I, I, P]),
+    "bdetr_layernorm_act_fwd": (I, [P, L, I, I, P, P, F, F, P, I, P]),
+    "bdetr_copy_cols": (I, [P, L, I, I, P, I, I, P]),
+    "bdetr_nhwc_to_nchw": (I, [P, I, I, I, I, P, P]),
     "bdetr_softmax_lastdim_fwd": (I, [P, P, L, I, P]),
     "bdetr_softmax_lastdim_bwd": (I, [P, P, P, L, I, P]),
     "bdetr_sigmoid_fwd": (I, [P, P, L, P]),

@@ -688,3 +688,44 @@ def set_loss(d: LossDesc, cat_pred, att_pred, box_pred, cat_ids, att_hot, bbox, 
     check(_lib.lib().bdetr_set_loss(C.byref(d), _p(cat_pred), _p(att_pred), _p(box_pred), _p(cat_ids), _p(att_hot), _p(bbox), _p(num_objects),
                                     _p(match), _p(losses), _p(d_cat), _p(d_att), _p(d_box), float(loss_scale), _stream()), "set_loss")
     return losses, d_cat, d_att, d_box
+
+
+# --------------------------------------------------------------------------------------
+# panoptic head pieces (forward only) - csrc/panoptic.hip
+# --------------------------------------------------------------------------------------
+def pad4(c: int) -> int:
+    return (c + 3) // 4 * 4
+
+
+def resize_bilinear(x, H: int, W: int):
+    _chk(x)
+    B, h, w, Cc = x.shape
+    out = empty(B, H, W, Cc, like=x)
+    check(_lib.lib().bdetr_resize_bilinear_nhwc(_p(x), B, h, w, Cc, _p(out), H, W, _stream()), "resize_bilinear")
+    return out
+
+
+def layernorm_act(x, C_true: int, gamma, beta, eps: float, slope: float = 1.0, ld_out: Optional[int] = None):
+    """LayerNormalization over the first C_true channels of x [..., ld] (+ leaky ReLU with `slope`); output [..., ld_out], pad = 0."""
+    _chk(x, gamma, beta)
+    ld = x.shape[-1]
+    ldo = pad4(C_true) if ld_out is None else ld_out
+    out = empty(*x.shape[:-1], ldo, like=x)
+    rows = x.numel() // ld
+    check(_lib.lib().bdetr_layernorm_act_fwd(_p(x), rows, C_true, ld, _p(gamma), _p(beta), eps, slope, _p(out), ldo, _stream()), "layernorm_act")
+    return out
+
+
+def copy_cols(src, C_true: int, dst, col0: int):
+    _chk(src, dst)
+    rows = src.numel() // src.shape[-1]
+    check(_lib.lib().bdetr_copy_cols(_p(src), rows, C_true, src.shape[-1], _p(dst), dst.shape[-1], col0, _stream()), "copy_cols")
+    return dst
+
+
+def nhwc_to_nchw(x, C_true: int):
+    _chk(x)
+    B, H, W, ld = x.shape
+    out = empty(B, C_true, H * W, like=x)
+    check(_lib.lib().bdetr_nhwc_to_nchw(_p(x), B, H * W, C_true, ld, _p(out), _stream()), "nhwc_to_nchw")
+    return out

@@ -244,3 +244,49 @@ class DecoderPrep(Layer):
         decoder_features = ops.tile_batch(self.init_decoder_features, B)
         decoder_positional = decoder_features
         return encoder_value, decoder_features, encoder_key, decoder_positional
+
+
+class PanopticAttention(Layer):
+    """transformers.py:460-559 ("not tested" in the reference, line 13), forward only.  Partial multi-head attention that
+    emits one image-sized map per decoder box: value / key / query are ALL projected from the flattened image encoding
+    (the reference feeds ``value`` to the key and query projections, lines 535-536 - reproduced), one softmax over the
+    full num_heads*key_dim width (no head split), value width = num_heads * num_obj, LayerNormalization (eps 1e-3) of the
+    result, reshaped to [B, rows, cols, num_obj, num_heads].  Dense layers use the Keras default glorot_uniform."""
+
+    def __init__(self, num_attention_heads, hidden_dim, name="PanopticAttention", **kwargs):
+        super().__init__(name=name, **kwargs)
+        self.num_attention_heads = num_attention_heads
+        self.hidden_dim = hidden_dim
+
+    def get_config(self):
+        c = super().get_config()
+        c.update({"num_attention_heads": self.num_attention_heads, "hidden_dim": self.hidden_dim})
+        return c
+
+    def build(self, input_shape):
+        self.image_encoding_shape, self.decoder_encoding_shape = input_shape[0], input_shape[1]
+        enc = self.image_encoding_shape[3]
+        self.num_obj = self.decoder_encoding_shape[1]
+        self.key_dim = max(1, self.hidden_dim // self.num_attention_heads)
+        h = self.num_attention_heads
+        self.ValueProjection = _Dense(self, "ValueProjection", enc, h * self.num_obj, "glorot_uniform")
+        self.KeyProjection = _Dense(self, "KeyProjection", enc, h * self.key_dim, "glorot_uniform")
+        self.QueryProjection = _Dense(self, "QueryProjection", enc, h * self.key_dim, "glorot_uniform")
+        self.ln_gamma, self.ln_beta = _layer_norm_vars(self, "LayerNorm", h * self.num_obj)
+
+    def call(self, inputs, training=False, self_attention_mask=None):
+        image_encoding, decoder_encoding, positional_encoding = inputs       # the last two only fix shapes (reference quirk)
+        B, r, c, E = image_encoding.shape
+        T = r * c
+        value = image_encoding.reshape(B * T, E).contiguous()
+        v = K.linear_fwd(value, self.ValueProjection.kernel.value, self.ValueProjection.bias.value)      # [B*T, h*num_obj]
+        k = K.linear_fwd(value, self.KeyProjection.kernel.value, self.KeyProjection.bias.value)          # [B*T, h*kd]
+        q = K.linear_fwd(value, self.QueryProjection.kernel.value, self.QueryProjection.bias.value)
+        D, Dv = k.shape[1], v.shape[1]
+        s = K.empty(B, T, T, like=value)
+        K.gemm_raw(T, T, D, q, D, True, k, D, True, s, T, nb0=B, sa=(T * D, 0), sb=(T * D, 0), sc=(T * T, 0))       # MatMul_1
+        p = K.softmax_rows_fwd(s.view(-1, T), 1.0 / math.sqrt(float(self.key_dim)), out=s.view(-1, T))               # Divide + Softmax
+        o = K.empty(B, T, Dv, like=value)
+        K.gemm_raw(T, Dv, T, p, T, True, v, Dv, False, o, Dv, nb0=B, sa=(T * T, 0), sb=(T * Dv, 0), sc=(T * Dv, 0))  # MatMul_2
+        o = K.layernorm_act(o, Dv, self.ln_gamma.value, self.ln_beta.value, LN_EPS, 1.0, ld_out=Dv)
+        return o.view(B, r, c, self.num_obj, Dv // self.num_obj)                                                       # ReshapeOutput

@@ -298,6 +298,23 @@ int bdetr_add_dropout_layernorm_bwd(const float* dout, const float* x, const flo
                                     float rate, uint64_t seed, const uint64_t* seed_base, int accumulate_dx, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Panoptic head (forward only - the reference never wires it into a loss):
+ * panoptic_neck.py:20-21 Resizing (bilinear, half-pixel centres), 118-121 / 164-167 channel LayerNormalization
+ * (eps 1e-3) + ReLU(negative_slope), 33-47 Concatenate / transpose; transformers.py:519 LayerNormalization.
+ * Channel counts of the head are arbitrary (66, 44, 29 ...): tensors are stored with the channel dimension
+ * zero-padded to a multiple of 4 (ld), and the convolutions run on bdetr_conv2d_fwd with zero-padded weights.
+ *   resize        in [B,h,w,C] -> out [B,H,W,C], C % 4 == 0
+ *   layernorm_act out[r][c] = leaky_slope(gamma[c] * (x[r][c] - mean_r) * rstd_r + beta[c]) for c < C, 0 for C <= c < ldo
+ *   copy_cols     dst[r][dst_col0 + c] = src[r][c], c < C            (channel concatenation / padding)
+ *   nhwc_to_nchw  out[b][c][p] = in[b][p][c], c < C of ld_in columns
+ * ---------------------------------------------------------------------- */
+int bdetr_resize_bilinear_nhwc(const float* in, int B, int h, int w, int C, float* out, int H, int W, void* stream);
+int bdetr_layernorm_act_fwd(const float* x, int64_t rows, int C, int ldx, const float* gamma, const float* beta,
+                            float eps, float slope, float* out, int ldo, void* stream);
+int bdetr_copy_cols(const float* src, int64_t rows, int C, int ld_src, float* dst, int ld_dst, int dst_col0, void* stream);
+int bdetr_nhwc_to_nchw(const float* in, int B, int P, int C, int ld_in, float* out, void* stream);
+
+/* ------------------------------------------------------------------------
  * K9  head activations (prediction_heads.py:44,60-62,111,127-129,180,197-199)
  * ---------------------------------------------------------------------- */
 int bdetr_softmax_lastdim_fwd(const float* logits, float* p, int64_t rows, int cols, void* stream);
