@@ -67,7 +67,7 @@ SIGNATURES = {
     "bdetr_conv2d_bwd_data": (I, [P, P, P, C.POINTER(ConvDesc), I, P]),
     "bdetr_conv2d_bwd_weight": (I, [P, P, P, C.POINTER(ConvDesc), I, P]),
     "bdetr_conv2d_bwd_weight_splitk": (I, [C.POINTER(ConvDesc)]),
-    "bdetr_bn_apply_p16": (I, [P, P, P, P, P, P, I, I, P, P, P, P, L, I, P]),
+    "bdetr_bn_apply_p16": (I, [P, P, P, P, P, P, I, I, P, P, P, P, P, L, I, P]),
     "bdetr_bn_bwd_p16": (I, [P, P, I, P, P, P, P, P, I, I, P, P, P, P, P, P, L, I, P]),
     "bdetr_p16_supported": (I, [C.POINTER(ConvDesc)]),
     "bdetr_p16_pack": (I, [P, L, P, P, P, P]),

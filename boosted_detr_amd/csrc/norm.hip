@@ -134,10 +134,18 @@ struct StatFn {
 // backward's recomputed ReLU mask round identically
 __device__ __forceinline__ float bn_affine(float v, float m, float rs, float g, float b) { return __builtin_fmaf(v - m, rs * g, b); }
 
+// ReLU bit mask written by bn_apply_p16 (1 bit per element instead of re-reading a 4-byte-per-element tensor in both
+// backward passes): element e of float4 index i lives in word (i >> 6) * 4 + e, bit i & 63
+__device__ __forceinline__ unsigned relu_mask_bits4(const void* mask, int64_t i) {
+    const unsigned long long* w = reinterpret_cast<const unsigned long long*>(mask) + (i >> 6) * 4;
+    const int b = (int)(i & 63);
+    return (unsigned)((w[0] >> b) & 1ull) | ((unsigned)((w[1] >> b) & 1ull) << 1) | ((unsigned)((w[2] >> b) & 1ull) << 2) | ((unsigned)((w[3] >> b) & 1ull) << 3);
+}
+
 struct BnBwdFn {   // a = g (masked dout), b = g * xhat
     const float* dout; const float* out; const float* x; const float* mean; const float* rstd; const float* gamma; const float* beta;
     int C; int relu;
-    int out_p16 = 0;      // `out` is the bf16 pair copy of the forward output (P16 layout), not the fp32 tensor
+    int out_p16 = 0;      // mask source `out`: 0 fp32 forward output, 1 its bf16 pair copy (P16 layout), 2 bn_apply_p16's ReLU bit mask
     __device__ __forceinline__ void operator()(int64_t r, int c, f32x4& a, f32x4& b) const {
         f32x4 g = *reinterpret_cast<const f32x4*>(dout + r * C + c);
         f32x4 xv = *reinterpret_cast<const f32x4*>(x + r * C + c);
@@ -145,7 +153,7 @@ struct BnBwdFn {   // a = g (masked dout), b = g * xhat
         f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + c);
         if (relu) {
             if (out != nullptr && out_p16) {
-                const unsigned pm = p16_positive4_bf16(out, (r * C + c) >> 2);
+                const unsigned pm = out_p16 == 2 ? relu_mask_bits4(out, (r * C + c) >> 2) : p16_positive4_bf16(out, (r * C + c) >> 2);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) if (!((pm >> e) & 1u)) g[e] = 0.f;
             } else if (out != nullptr) {
@@ -227,8 +235,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 __global__ __launch_bounds__(256) void bn_apply_p16_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const void* __restrict__ residual, int residual_p16, int relu, float* __restrict__ out32,
-                                                           void* __restrict__ out_f16, void* __restrict__ out_bf16, int* __restrict__ overflow_flag,
-                                                           int64_t n4, int c4n) {
+                                                           void* __restrict__ out_f16, void* __restrict__ out_bf16, unsigned long long* __restrict__ relu_mask,
+                                                           int* __restrict__ overflow_flag, int64_t n4, int c4n) {
     // n4 is even and the stride is even: the two lanes of a pair (one 8-element group) always run together
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % c4n) * 4;
@@ -251,6 +259,14 @@ __global__ __launch_bounds__(256) void bn_apply_p16_kernel(const float* __restri
         if (relu) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+        }
+        if (relu_mask != nullptr) {
+            // a wave covers 64 consecutive float4 indices (256-thread blocks, strides that are multiples of 256)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned long long m = __ballot(o[e] > 0.f);
+                if ((i & 63) == 0) relu_mask[(i >> 6) * 4 + e] = m;
+            }
         }
         if (out32 != nullptr) reinterpret_cast<f32x4*>(out32)[i] = o;
         if (out_f16 != nullptr) {
@@ -280,7 +296,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_p16_kernel(const float* __re
         if (!frozen || recompute) xv = reinterpret_cast<const f32x4*>(x)[i];
         if (relu) {
             if (!recompute && out_p16) {
-                const unsigned pm = p16_positive4_bf16(out, i);
+                const unsigned pm = out_p16 == 2 ? relu_mask_bits4(out, i) : p16_positive4_bf16(out, i);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) if (!((pm >> e) & 1u)) g[e] = 0.f;
             } else if (!recompute) {
@@ -576,12 +592,12 @@ extern "C" int bdetr_bn_bwd(const float* dout, const float* out, const float* x,
 
 extern "C" int bdetr_bn_apply_p16(const float* x, const float* mean, const float* rstd, const float* gamma,
                                   const float* beta, const void* residual, int residual_p16, int relu, float* out32, void* out_f16, void* out_bf16,
-                                  int* overflow_flag, int64_t rows, int C, void* stream) {
+                                  uint64_t* relu_mask, int* overflow_flag, int64_t rows, int C, void* stream) {
     BDETR_CHECK_ARG(x && mean && rstd && gamma && beta && (out32 || out_f16 || out_bf16) && rows > 0 && C > 0 && C % 8 == 0,
                     "bdetr_bn_apply_p16: bad arguments (C %% 8 == 0 required)");
     const int64_t n4 = rows * C / 4;
     hipLaunchKernelGGL(bn_apply_p16_kernel, dim3(ew_grid(n4, 256, 2)), dim3(256), 0, (hipStream_t)stream, x, mean, rstd, gamma, beta, residual, residual_p16, relu,
-                       out32, out_f16, out_bf16, overflow_flag, n4, C / 4);
+                       out32, out_f16, out_bf16, reinterpret_cast<unsigned long long*>(relu_mask), overflow_flag, n4, C / 4);
     return bdetr_launch_status("bn_apply_p16");
 }
 

@@ -279,24 +279,29 @@ def p16_pack_conv_weights(w, want_fwd=True, want_bwd=True):
 
 
 def bn_apply_p16(x2d, mean, rstd, gamma, beta, residual=None, relu=False, want_fp32=True, want_f16=True, want_bf16=True,
-                 residual_p16=False):
-    """bn_apply with P16 outputs: returns (out32 | None, out_f16 | None, out_bf16 | None).  residual_p16: `residual`
-    is the f16 pair copy of the shortcut tensor."""
+                 residual_p16=False, want_mask=False):
+    """bn_apply with P16 outputs: returns (out32 | None, out_f16 | None, out_bf16 | None[, relu bit mask]).  residual_p16:
+    `residual` is the f16 pair copy of the shortcut tensor.  want_mask: also return the 1-bit-per-element ReLU mask
+    (int64 words) the backward pass of a residual unit reads instead of the forward output."""
     _chk(x2d, mean, rstd, gamma, beta, residual)
     rows, Cc = x2d.shape
     o32 = torch.empty_like(x2d) if want_fp32 else None
     of = torch.empty_like(x2d) if want_f16 else None
     ob = torch.empty_like(x2d) if want_bf16 else None
+    mask = torch.empty(((rows * Cc // 4 + 63) // 64) * 4, dtype=torch.int64, device=x2d.device) if want_mask else None
     check(_lib.lib().bdetr_bn_apply_p16(_p(x2d), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(residual), int(residual_p16), int(relu), _p(o32),
-                                        _p(of), _p(ob), _p(overflow_flag()) if want_f16 else None, rows, Cc, _stream()), "bn_apply_p16")
-    return o32, of, ob
+                                        _p(of), _p(ob), _p(mask), _p(overflow_flag()) if want_f16 else None, rows, Cc, _stream()), "bn_apply_p16")
+    return (o32, of, ob, mask) if want_mask else (o32, of, ob)
 
 
 def bn_bwd_p16(dout, out, x2d, mean, rstd, gamma, relu, frozen, want_residual_grad=False, dgamma=None, dbeta=None, beta=None, want_fp32=False,
                out_p16=False):
     """bn_bwd writing the input gradient as a bf16 pair: returns (dx_bf16, dx32 | None, dgamma, dbeta, dres | None).
-    out_p16: the ReLU mask source `out` is the bf16 pair copy of the forward output."""
-    _chk(dout, out, x2d, mean, rstd, gamma, dgamma, dbeta)
+    out_p16: what the ReLU mask source `out` is - 0 / False the fp32 forward output, 1 / True its bf16 pair copy, 2 the bit
+    mask of bn_apply_p16(want_mask=True)."""
+    _chk(dout, x2d, mean, rstd, gamma, dgamma, dbeta)
+    if out is not None and int(out_p16) != 2:
+        _chk(out)
     L = _lib.lib()
     rows, Cc = x2d.shape
     dxb = torch.empty_like(x2d)

@@ -236,7 +236,7 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
     if residual is not None and not res_p16:
         residual = as_fp32(residual)
     res2d = _2d(residual) if residual is not None else None     # a P16-only handle IS its f16 pair copy
-    xb = ob = None
+    xb = ob = relu_bits = None
     if p16:
         xf, xb = _packed_input(x, need_bf16=w.needs_grad)
         wf, _ = packed_weights(w, need_bwd=False)
@@ -244,8 +244,11 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
         y2d = _2d(y)
         mean, rstd = K.bn_stats(g.M, Kout, parts, bn.eps, bn.momentum, True, bn.moving_mean.value, bn.moving_var.value, like=y2d)
         fp32_out = want_fp32 or not want_p16
-        o32, of, ob = K.bn_apply_p16(y2d, mean, rstd, bn.gamma.value, bn.beta.value, res2d, relu,
-                                     want_fp32=fp32_out, want_f16=want_p16, want_bf16=want_p16, residual_p16=res_p16)
+        # a residual unit without an fp32 output: its backward ReLU mask is a 1-bit-per-element by-product of this pass
+        want_mask = relu and residual is not None and not fp32_out
+        o32, of, ob, *rest = K.bn_apply_p16(y2d, mean, rstd, bn.gamma.value, bn.beta.value, res2d, relu, want_fp32=fp32_out,
+                                            want_f16=want_p16, want_bf16=want_p16, residual_p16=res_p16, want_mask=want_mask)
+        relu_bits = rest[0] if want_mask else None
         out2d = o32
         out = (o32 if fp32_out else of).view(N, g.OH, g.OW, Kout)
         if want_p16:
@@ -264,9 +267,13 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
             sg, sb = GradSink(bn.gamma), GradSink(bn.beta)
             # ReLU mask: recomputed from y when there is no residual, else read from the forward output (fp32, or the
             # hi halves of its bf16 pair copy when the output was never materialised in fp32)
-            mask_src = (out2d if out2d is not None else ob) if (relu and want_res) else None
+            # ReLU mask: recomputed from y when there is no residual, else the forward output (fp32), or - when that was never
+            # materialised in fp32 - the bit mask bn_apply wrote (else the hi halves of the bf16 pair copy)
+            mask_src, mode = None, 0
+            if relu and want_res:
+                mask_src, mode = (out2d, 0) if out2d is not None else ((relu_bits, 2) if relu_bits is not None else (ob, 1))
             dyb, _, _, _, dres = K.bn_bwd_p16(g2d, mask_src, y2d, mean, rstd, bn.gamma.value, relu, False, want_residual_grad=want_res,
-                                              dgamma=sg.buf, dbeta=sb.buf, beta=bn.beta.value, out_p16=mask_src is not None and out2d is None)
+                                              dgamma=sg.buf, dbeta=sb.buf, beta=bn.beta.value, out_p16=mode)
             sg.commit()
             sb.commit()
             dyb4 = dyb.view(N, g.OH, g.OW, Kout)

@@ -146,11 +146,15 @@ int bdetr_conv2d_bwd_weight_splitk(const bdetr_conv_desc* d);
  * arithmetic) with P16 outputs for the consumer convolutions: out_f16 = forward operand, out_bf16 = weight-
  * gradient operand, out32 = the fp32 tensor; any of the three may be null.  residual_p16 != 0: `residual` is the
  * f16 pair copy of the shortcut tensor (block outputs need not exist in fp32).  bdetr_bn_bwd_p16 writes the input
- * gradient as a bf16 pair (dx_bf16) and, when dx32 != null, in fp32 too; out_p16 != 0: the ReLU mask source `out`
- * is the bf16 pair copy of the forward output (its hi half has fp32's range: hi > 0 <=> value > 0). */
+ * gradient as a bf16 pair (dx_bf16) and, when dx32 != null, in fp32 too.  ReLU mask source of the backward pass
+ * (`out`, needed only when a residual was added - otherwise the mask is recomputed from x): out_p16 = 0 the fp32
+ * forward output, 1 its bf16 pair copy (the hi half has fp32's range: hi > 0 <=> value > 0), 2 the bit mask that
+ * bdetr_bn_apply_p16 writes to relu_mask (uint64 words, (rows*C/4 + 63)/64*4 of them: one bit per element instead of
+ * re-reading a 4-byte-per-element tensor in both backward passes). */
 int bdetr_bn_apply_p16(const float* x, const float* mean, const float* rstd, const float* gamma,
                        const float* beta, const void* residual, int residual_p16, int relu, float* out32,
-                       void* out_f16, void* out_bf16, int* overflow_flag, int64_t rows, int C, void* stream);
+                       void* out_f16, void* out_bf16, uint64_t* relu_mask, int* overflow_flag, int64_t rows, int C,
+                       void* stream);
 int bdetr_bn_bwd_p16(const float* dout, const void* out, int out_p16, const float* x, const float* mean,
                      const float* rstd, const float* gamma, const float* beta, int relu, int frozen,
                      float* dx32, void* dx_bf16, float* dgamma, float* dbeta, float* dresidual,

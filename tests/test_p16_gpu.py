@@ -177,3 +177,9 @@ def test_bn_p16_producers_match_the_fp32_kernels(cuda, rows, C, relu, res):
             dxb3, dx33, dg3, db3, dres3 = k.bn_bwd_p16(dout, ob, xd, mean, rstd, gamma, relu, False, want_residual_grad=True, beta=beta,
                                                        want_fp32=True, out_p16=True)
             assert torch.equal(dx33, dx) and torch.equal(dres3, dres) and torch.equal(dg3, dg) and torch.equal(db3, db)
+            # ... and from the 1-bit-per-element mask that bn_apply_p16 writes on request
+            o4, _, _, bits_ = k.bn_apply_p16(xd, mean, rstd, gamma, beta, dev(resid), relu, want_f16=False, want_bf16=False, want_mask=True)
+            assert torch.equal(o4, want)
+            dxb4, dx34, dg4, db4, dres4 = k.bn_bwd_p16(dout, bits_, xd, mean, rstd, gamma, relu, False, want_residual_grad=True, beta=beta,
+                                                       want_fp32=True, out_p16=2)
+            assert torch.equal(dx34, dx) and torch.equal(dres4, dres) and torch.equal(dg4, dg) and torch.equal(db4, db)
