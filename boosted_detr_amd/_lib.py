@@ -33,6 +33,11 @@ class GemmDesc(C.Structure):
     ]
 
 
+class BnBwdFuse(C.Structure):
+    _fields_ = [("y", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("relu", C.c_int),
+                ("part_g", C.c_void_p), ("part_gx", C.c_void_p)]
+
+
 class LossDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("M", C.c_int), ("N", C.c_int), ("C", C.c_int), ("A", C.c_int),
                 ("category_weight", C.c_float), ("attribute_weight", C.c_float),
@@ -68,7 +73,7 @@ SIGNATURES = {
     "bdetr_conv2d_bwd_weight": (I, [P, P, P, C.POINTER(ConvDesc), I, P]),
     "bdetr_conv2d_bwd_weight_splitk": (I, [C.POINTER(ConvDesc)]),
     "bdetr_bn_apply_p16": (I, [P, P, P, P, P, P, I, I, P, P, P, P, P, L, I, P]),
-    "bdetr_bn_bwd_p16": (I, [P, P, I, P, P, P, P, P, I, I, P, P, P, P, P, P, L, I, P]),
+    "bdetr_bn_bwd_p16": (I, [P, P, I, P, P, P, P, P, I, I, P, P, P, P, P, P, P, P, I, L, I, P]),
     "bdetr_p16_supported": (I, [C.POINTER(ConvDesc)]),
     "bdetr_p16_pack": (I, [P, L, P, P, P, P]),
     "bdetr_p16_unpack": (I, [P, I, L, P, P]),
@@ -77,6 +82,8 @@ SIGNATURES = {
     "bdetr_p16_conv2d_fwd_stat_chunks": (I, [C.POINTER(ConvDesc)]),
     "bdetr_p16_conv2d_fwd": (I, [P, P, P, P, C.POINTER(ConvDesc), I, P, P, P]),
     "bdetr_p16_conv2d_bwd_data": (I, [P, P, P, C.POINTER(ConvDesc), I, P]),
+    "bdetr_p16_conv2d_bwd_data_stat_chunks": (I, [C.POINTER(ConvDesc)]),
+    "bdetr_p16_conv2d_bwd_data_bnstats": (I, [P, P, P, C.POINTER(ConvDesc), C.POINTER(BnBwdFuse), P]),
     "bdetr_p16_conv2d_bwd_weight_splitk": (I, [C.POINTER(ConvDesc)]),
     "bdetr_p16_conv2d_bwd_weight": (I, [P, P, P, C.POINTER(ConvDesc), I, P]),
     "bdetr_gemm": (I, [C.POINTER(GemmDesc), P]),

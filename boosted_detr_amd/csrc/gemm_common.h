@@ -27,6 +27,12 @@ struct GemmParams {
     // share J, R and the epilogue flags but have their own pointers and row count (Q/K/V projections)
     int ngroups;
     const float* ga[4]; const float* gb[4]; float* gc[4]; const float* gbias[4]; int gI[4];
+    // Fused BatchNorm-backward reduction (backward-data launches whose output IS the gradient of a BatchNorm(+ReLU) output
+    // y' = relu?(gamma * (y - mean) * rstd + beta) with no residual): while the C tile passes through the epilogue, its
+    // columns' partial sums of g = C * [y' > 0] and g * xhat are written to bnb_sum_g / bnb_sum_gx [tiles_i][J] - the pass
+    // that would re-read C and y (colreduce2<BnBwdFn>) disappears.  bnb_y has C's shape and leading dimension.
+    const float* bnb_y; const float* bnb_mean; const float* bnb_rstd; const float* bnb_gamma; const float* bnb_beta;
+    int bnb_relu; float* bnb_sum_g; float* bnb_sum_gx;
 };
 
 inline void init_params(GemmParams& g) {
@@ -109,6 +115,14 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
                     lds[(wm * WTM + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * CLD + wn * WTN + b * 32 + li] = acc[a][b][e];
         __syncthreads();
         constexpr int V_PER_ROW = BN / 4;
+        static_assert(NT % V_PER_ROW == 0, "a thread keeps one column group");
+        const bool bnb = g.bnb_y != nullptr;
+        const int jc = j0 + 4 * (tid % V_PER_ROW);               // this thread's 4 columns (the same in every iteration)
+        f32x4 bm = {0, 0, 0, 0}, brs = bm, bgm = bm, bbt = bm, sg = bm, sgx = bm;
+        if (bnb && jc < g.J) {
+            bm = *reinterpret_cast<const f32x4*>(g.bnb_mean + jc); brs = *reinterpret_cast<const f32x4*>(g.bnb_rstd + jc);
+            bgm = *reinterpret_cast<const f32x4*>(g.bnb_gamma + jc); bbt = *reinterpret_cast<const f32x4*>(g.bnb_beta + jc);
+        }
 #pragma unroll
         for (int v = tid; v < BM * V_PER_ROW; v += NT) {
             const int r = v / V_PER_ROW, c4 = v - r * V_PER_ROW;
@@ -118,6 +132,34 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
                 f32x4* dst = reinterpret_cast<f32x4*>(cbase + out_row(i) * g.ldc + j);
                 if (g.mode == ST_ACCUM) val += *dst;
                 *dst = val;
+                if (bnb) {
+                    const f32x4 yv = *reinterpret_cast<const f32x4*>(g.bnb_y + (int64_t)i * g.ldc + j);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool on = !g.bnb_relu || (__builtin_fmaf(yv[e] - bm[e], brs[e] * bgm[e], bbt[e]) > 0.f);      // = norm.hip's bn_affine
+                        const float ge = on ? val[e] : 0.f;
+                        sg[e] += ge; sgx[e] += ge * ((yv[e] - bm[e]) * brs[e]);
+                    }
+                }
+            }
+        }
+        if (bnb) {
+            // fold the NT / V_PER_ROW threads that share a column group (fixed order), one partial row per tile_i
+            constexpr int G = NT / V_PER_ROW;
+            static_assert(NT * 8 <= LDS_FLOATS, "reduction scratch must fit");
+            __syncthreads();                                      // every thread is done reading the C tile
+            *reinterpret_cast<f32x4*>(lds + tid * 8) = sg;
+            *reinterpret_cast<f32x4*>(lds + tid * 8 + 4) = sgx;
+            __syncthreads();
+            if (tid < V_PER_ROW && jc < g.J) {
+                f32x4 a = {0, 0, 0, 0}, b = a;
+#pragma unroll
+                for (int k = 0; k < G; ++k) {
+                    a += *reinterpret_cast<const f32x4*>(lds + (tid + k * V_PER_ROW) * 8);
+                    b += *reinterpret_cast<const f32x4*>(lds + (tid + k * V_PER_ROW) * 8 + 4);
+                }
+                *reinterpret_cast<f32x4*>(g.bnb_sum_g + (int64_t)tile_i * g.J + jc) = a;
+                *reinterpret_cast<f32x4*>(g.bnb_sum_gx + (int64_t)tile_i * g.J + jc) = b;
             }
         }
         return;

@@ -604,18 +604,23 @@ extern "C" int bdetr_bn_apply_p16(const float* x, const float* mean, const float
 extern "C" int bdetr_bn_bwd_p16(const float* dout, const void* out, int out_p16, const float* x, const float* mean,
                                 const float* rstd, const float* gamma, const float* beta, int relu, int frozen,
                                 float* dx32, void* dx_bf16, float* dgamma, float* dbeta, float* dresidual,
-                                float* ws, int64_t rows, int C, void* stream) {
-    BDETR_CHECK_ARG(dout && x && mean && rstd && gamma && dx_bf16 && dgamma && dbeta && ws && rows > 0 && C > 0 && C % 8 == 0,
+                                float* ws, const float* pre_g, const float* pre_gx, int pre_n, int64_t rows, int C, void* stream) {
+    BDETR_CHECK_ARG(dout && x && mean && rstd && gamma && dx_bf16 && dgamma && dbeta && (ws || pre_g) && rows > 0 && C > 0 && C % 8 == 0,
                     "bdetr_bn_bwd_p16: bad arguments (C %% 8 == 0 required)");
+    BDETR_CHECK_ARG((pre_g == nullptr) == (pre_gx == nullptr) && (pre_g == nullptr || pre_n > 0), "bdetr_bn_bwd_p16: pre_g / pre_gx / pre_n inconsistent");
     BDETR_CHECK_ARG(!relu || out || beta, "bdetr_bn_bwd_p16: relu needs the forward output, or beta to recompute the mask from x");
     hipStream_t st = (hipStream_t)stream;
     ColGeom g = col_geom(C);
     int64_t rpc = chunk_rows_for(rows, chunks_for_width(g.gx), 64);   // <= bdetr_bn_bwd_chunks(rows), which sizes ws
     int nch = (int)cdiv64(rows, rpc);
     float* pa = ws; float* pb = ws + (int64_t)nch * C;
-    BnBwdFn f{dout, reinterpret_cast<const float*>(out), x, mean, rstd, gamma, beta, C, relu, out_p16};
-    hipLaunchKernelGGL((colreduce2_kernel<BnBwdFn>), dim3(g.gx, nch), dim3(256), 0, st, f, rows, C, g.tx, rpc, pa, pb);
-    hipLaunchKernelGGL(sum_partials2_kernel, dim3((C + 7) / 8), dim3(256), 0, st, pa, pb, nch, C, dbeta, dgamma);
+    if (pre_g != nullptr) {
+        hipLaunchKernelGGL(sum_partials2_kernel, dim3((C + 7) / 8), dim3(256), 0, st, pre_g, pre_gx, pre_n, C, dbeta, dgamma);
+    } else {
+        BnBwdFn f{dout, reinterpret_cast<const float*>(out), x, mean, rstd, gamma, beta, C, relu, out_p16};
+        hipLaunchKernelGGL((colreduce2_kernel<BnBwdFn>), dim3(g.gx, nch), dim3(256), 0, st, f, rows, C, g.tx, rpc, pa, pb);
+        hipLaunchKernelGGL(sum_partials2_kernel, dim3((C + 7) / 8), dim3(256), 0, st, pa, pb, nch, C, dbeta, dgamma);
+    }
     const int64_t n4 = rows * C / 4;
     hipLaunchKernelGGL(bn_bwd_apply_p16_kernel, dim3(ew_grid(n4, 256, 2)), dim3(256), 0, st, dout, out, out_p16, x, mean, rstd, gamma, beta, dgamma, dbeta,
                        relu, frozen, dx32, dx_bf16, dresidual, n4, C / 4, 1.0f / (float)rows);

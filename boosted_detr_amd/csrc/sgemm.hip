@@ -511,16 +511,36 @@ extern "C" int bdetr_p16_conv2d_fwd(const void* x_f16, const void* w_f16, const 
     return launch_any<RRPatch, RRDense, false, true>(xop, wop, g, 1, st, 1000, tile);
 }
 
+static int bwd_data_tile(const bdetr_conv_desc* d) {
+    const bool dense = d->R == 1 && d->S == 1 && d->pad == 0;
+    return choose_tile(dense ? (int64_t)d->N * d->OH * d->OW : (int64_t)d->N * d->H * d->W, d->C, 1);
+}
+
+// number of partial rows bdetr_p16_conv2d_bwd_data writes per statistic when the BatchNorm-backward reduction is fused
+extern "C" int bdetr_p16_conv2d_bwd_data_stat_chunks(const bdetr_conv_desc* d) {
+    if (check_conv(d, "bdetr_p16_conv2d_bwd_data_stat_chunks")) return -1;
+    const bool dense = d->R == 1 && d->S == 1 && d->pad == 0;
+    return (int)cdiv64(dense ? (int64_t)d->N * d->OH * d->OW : (int64_t)d->N * d->H * d->W, TILE_BM[bwd_data_tile(d)]);
+}
+
 // dy_bf16: P16-bf16 [N,OH,OW,K]; wt_bf16: the transposed / tap-flipped P16-bf16 weight copy [C][R*S][K]
-// (bdetr_p16_pack_conv_weights); dx: fp32 [N,H,W,C]
-extern "C" int bdetr_p16_conv2d_bwd_data(const void* dy_bf16, const void* wt_bf16, float* dx,
-                                         const bdetr_conv_desc* d, int accumulate, void* stream) {
+// (bdetr_p16_pack_conv_weights); dx: fp32 [N,H,W,C].  bn (may be null): dx is the gradient of the BatchNorm(+ReLU) output
+// whose pre-normalisation tensor is bn->y - fuse that layer's backward reduction into this epilogue.
+static int p16_bwd_data(const void* dy_bf16, const void* wt_bf16, float* dx, const bdetr_conv_desc* d, int accumulate,
+                        const bdetr_bn_bwd_fuse* bn, void* stream) {
     if (int e = check_conv(d, "bdetr_p16_conv2d_bwd_data")) return e;
     BDETR_CHECK_ARG(dy_bf16 && wt_bf16 && dx, "bdetr_p16_conv2d_bwd_data: null pointer");
     hipStream_t st = (hipStream_t)stream;
     const int M = d->N * d->OH * d->OW;
     GemmParams g; init_params(g);
     g.c = dx; g.ldc = d->C; g.mode = accumulate ? ST_ACCUM : ST_STORE;
+    if (bn != nullptr) {
+        BDETR_CHECK_ARG(!accumulate && d->stride == 1 && d->C % 4 == 0 && aligned16(dx) && aligned16(bn->y),
+                        "bdetr_p16_conv2d_bwd_data_bnstats: needs a plain store of 16-byte aligned rows (no accumulate, stride 1)");
+        BDETR_CHECK_ARG(bn->y && bn->mean && bn->rstd && bn->gamma && bn->beta && bn->part_g && bn->part_gx, "bdetr_p16_conv2d_bwd_data_bnstats: null pointer");
+        g.bnb_y = bn->y; g.bnb_mean = bn->mean; g.bnb_rstd = bn->rstd; g.bnb_gamma = bn->gamma; g.bnb_beta = bn->beta;
+        g.bnb_relu = bn->relu; g.bnb_sum_g = bn->part_g; g.bnb_sum_gx = bn->part_gx;
+    }
     if (d->R == 1 && d->S == 1 && d->pad == 0) {
         g.I = M; g.J = d->C; g.R = d->K;
         if (d->stride > 1) {
@@ -532,7 +552,7 @@ extern "C" int bdetr_p16_conv2d_bwd_data(const void* dy_bf16, const void* wt_bf1
         }
         PDense a{dy_bf16, (unsigned)d->K, M, d->K};
         PDense b{wt_bf16, (unsigned)d->K, d->C, d->K};
-        return launch_any<RRDense, RRDense, false, false>(a, b, g, 1, st, 0, choose_tile(M, d->C, 1));
+        return launch_any<RRDense, RRDense, false, false>(a, b, g, 1, st, 0, bwd_data_tile(d));
     }
     BDETR_CHECK_ARG(d->stride == 1 && d->R == d->S, "bdetr_p16_conv2d_bwd_data: stride>1 only for 1x1 convs; square kernels only");
     BDETR_CHECK_ARG(d->K % BK == 0, "bdetr_p16_conv2d_bwd_data: K %% %d == 0 required for kernels larger than 1x1", BK);
@@ -541,7 +561,17 @@ extern "C" int bdetr_p16_conv2d_bwd_data(const void* dy_bf16, const void* wt_bf1
     g.I = Mx; g.J = d->C; g.R = Kd;
     PPatch a = make_patch(dy_bf16, d->N, d->OH, d->OW, d->K, d->H, d->W, d->R, d->S, 1, d->R - 1 - d->pad, Mx, Kd);
     PDense b{wt_bf16, (unsigned)Kd, d->C, Kd};
-    return launch_any<RRPatch, RRDense, false, false>(a, b, g, 1, st, 1000, choose_tile(Mx, d->C, 1));
+    return launch_any<RRPatch, RRDense, false, false>(a, b, g, 1, st, 1000, bwd_data_tile(d));
+}
+
+extern "C" int bdetr_p16_conv2d_bwd_data(const void* dy_bf16, const void* wt_bf16, float* dx,
+                                         const bdetr_conv_desc* d, int accumulate, void* stream) {
+    return p16_bwd_data(dy_bf16, wt_bf16, dx, d, accumulate, nullptr, stream);
+}
+extern "C" int bdetr_p16_conv2d_bwd_data_bnstats(const void* dy_bf16, const void* wt_bf16, float* dx,
+                                                 const bdetr_conv_desc* d, const bdetr_bn_bwd_fuse* bn, void* stream) {
+    BDETR_CHECK_ARG(bn != nullptr, "bdetr_p16_conv2d_bwd_data_bnstats: null bn descriptor");
+    return p16_bwd_data(dy_bf16, wt_bf16, dx, d, 0, bn, stream);
 }
 
 static int wgrad_tile(const bdetr_conv_desc* d) {

@@ -13,7 +13,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, GemmDesc, LossDesc, check
+from ._lib import BnBwdFuse, ConvDesc, GemmDesc, LossDesc, check
 
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 
@@ -295,7 +295,7 @@ def bn_apply_p16(x2d, mean, rstd, gamma, beta, residual=None, relu=False, want_f
 
 
 def bn_bwd_p16(dout, out, x2d, mean, rstd, gamma, relu, frozen, want_residual_grad=False, dgamma=None, dbeta=None, beta=None, want_fp32=False,
-               out_p16=False):
+               out_p16=False, pre=None):
     """bn_bwd writing the input gradient as a bf16 pair: returns (dx_bf16, dx32 | None, dgamma, dbeta, dres | None).
     out_p16: what the ReLU mask source `out` is - 0 / False the fp32 forward output, 1 / True its bf16 pair copy, 2 the bit
     mask of bn_apply_p16(want_mask=True)."""
@@ -309,9 +309,11 @@ def bn_bwd_p16(dout, out, x2d, mean, rstd, gamma, relu, frozen, want_residual_gr
     dgamma = empty(Cc, like=x2d) if dgamma is None else dgamma
     dbeta = empty(Cc, like=x2d) if dbeta is None else dbeta
     dres = torch.empty_like(x2d) if want_residual_grad else None
-    ws = empty(2 * Cc * L.bdetr_bn_bwd_chunks(rows), like=x2d)
+    # pre = (part_g, part_gx, nparts): the reduction already done by the backward-data epilogue that produced dout
+    ws = empty(2 * Cc * L.bdetr_bn_bwd_chunks(rows), like=x2d) if pre is None else None
+    pg, pgx, pn = pre if pre is not None else (None, None, 0)
     check(L.bdetr_bn_bwd_p16(_p(dout), _p(out), int(out_p16), _p(x2d), _p(mean), _p(rstd), _p(gamma), _p(beta), int(relu), int(frozen), _p(dx32),
-                             _p(dxb), _p(dgamma), _p(dbeta), _p(dres), _p(ws), rows, Cc, _stream()), "bn_bwd_p16")
+                             _p(dxb), _p(dgamma), _p(dbeta), _p(dres), _p(ws), _p(pg), _p(pgx), int(pn), rows, Cc, _stream()), "bn_bwd_p16")
     return dxb, dx32, dgamma, dbeta, dres
 
 
@@ -346,6 +348,22 @@ def p16_conv2d_bwd_data(dy_bf16, wt_bf16, g: ConvGeom, dx: Optional[torch.Tensor
         dx = empty(g.N, g.H, g.W, g.C, like=dy_bf16)
     check(_lib.lib().bdetr_p16_conv2d_bwd_data(_p(dy_bf16), _p(wt_bf16), _p(dx), C.byref(d), int(accumulate), _stream()), "p16_conv2d_bwd_data")
     return dx
+
+
+def p16_conv2d_bwd_data_bnstats(dy_bf16, wt_bf16, g: ConvGeom, y_prev, mean, rstd, gamma, beta, relu: bool):
+    """Backward-data whose output is the gradient of the BatchNorm(+ReLU) output that fed this conv (pre-normalisation tensor
+    y_prev, no residual): returns (dx, (part_g, part_gx, nparts)) - that layer's backward reduction, done in this epilogue."""
+    _chk(dy_bf16, wt_bf16, y_prev, mean, rstd, gamma, beta)
+    L = _lib.lib()
+    d = g.desc()
+    dx = empty(g.N, g.H, g.W, g.C, like=dy_bf16)
+    n = L.bdetr_p16_conv2d_bwd_data_stat_chunks(C.byref(d))
+    if n <= 0:
+        check(-1, "p16_conv2d_bwd_data_stat_chunks")
+    pg, pgx = empty(n, g.C, like=dy_bf16), empty(n, g.C, like=dy_bf16)
+    f = BnBwdFuse(_p(y_prev), _p(mean), _p(rstd), _p(gamma), _p(beta), int(relu), _p(pg), _p(pgx))
+    check(L.bdetr_p16_conv2d_bwd_data_bnstats(_p(dy_bf16), _p(wt_bf16), _p(dx), C.byref(d), C.byref(f), _stream()), "p16_conv2d_bwd_data_bnstats")
+    return dx, (pg, pgx, n)
 
 
 def p16_conv2d_bwd_weight(x_bf16, dy_bf16, g: ConvGeom, dw: Optional[torch.Tensor] = None, prezeroed: bool = False):

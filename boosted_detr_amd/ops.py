@@ -253,6 +253,10 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
         out = (o32 if fp32_out else of).view(N, g.OH, g.OW, Kout)
         if want_p16:
             out._p16f, out._p16b, out._p16_only = of.view(out.shape), ob.view(out.shape), not fp32_out
+        if not fp32_out and residual is None and os.environ.get("BDETR_BN_FUSE", "1") != "0":
+            # a link with exactly one consumer (the next conv of the bottleneck): that conv's backward-data epilogue can do
+            # THIS BatchNorm's backward reduction while it stores the gradient (ops: see `backward` below)
+            out._bn_ctx = (y2d, mean, rstd, bn.gamma.value, bn.beta.value, relu)
     else:
         x = as_fp32(x)
         y, parts = K.conv2d_fwd(x, w.value, b.value, g, K.ACT_NONE, want_stats=use_batch)
@@ -272,8 +276,9 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
             mask_src, mode = None, 0
             if relu and want_res:
                 mask_src, mode = (out2d, 0) if out2d is not None else ((relu_bits, 2) if relu_bits is not None else (ob, 1))
+            pre = getattr(g_out, "_bnb_parts", None)        # the reduction came with the gradient (fused into the consumer's epilogue)
             dyb, _, _, _, dres = K.bn_bwd_p16(g2d, mask_src, y2d, mean, rstd, bn.gamma.value, relu, False, want_residual_grad=want_res,
-                                              dgamma=sg.buf, dbeta=sb.buf, beta=bn.beta.value, out_p16=mode)
+                                              dgamma=sg.buf, dbeta=sb.buf, beta=bn.beta.value, out_p16=mode, pre=pre)
             sg.commit()
             sb.commit()
             dyb4 = dyb.view(N, g.OH, g.OW, Kout)
@@ -291,9 +296,14 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
             dx = None
             if x_needs_grad:
                 _, wt = packed_weights(w, need_bwd=True)
+                ctx = getattr(x_handle, "_bn_ctx", None)
                 if acc is not None and acc[0] is not None:
                     K.p16_conv2d_bwd_data(dyb4, wt, g, dx=acc[0].view(N, H, W, Cin), accumulate=True)
                     dx = acc[0]
+                elif ctx is not None and stride == 1:
+                    dx, parts = K.p16_conv2d_bwd_data_bnstats(dyb4, wt, g, *ctx)
+                    dx = _own(dx)
+                    dx._bnb_parts = parts
                 else:
                     dx = _own(K.p16_conv2d_bwd_data(dyb4, wt, g))
             return dx, (_own(dres.view(residual.shape)) if want_res else None)

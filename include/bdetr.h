@@ -158,7 +158,9 @@ int bdetr_bn_apply_p16(const float* x, const float* mean, const float* rstd, con
 int bdetr_bn_bwd_p16(const float* dout, const void* out, int out_p16, const float* x, const float* mean,
                      const float* rstd, const float* gamma, const float* beta, int relu, int frozen,
                      float* dx32, void* dx_bf16, float* dgamma, float* dbeta, float* dresidual,
-                     float* ws, int64_t rows, int C, void* stream);
+                     float* ws, const float* pre_g, const float* pre_gx, int pre_n, int64_t rows, int C, void* stream);
+/* pre_g / pre_gx [pre_n][C] (may be null): partial sums of g and g * xhat already produced by the backward-data
+ * epilogue that wrote dout (bdetr_p16_conv2d_bwd_data_bnstats); the reduction pass over dout and x is skipped. */
 int bdetr_p16_supported(const bdetr_conv_desc* d);
 int bdetr_p16_pack(const float* x, int64_t n, void* f16_out, void* bf16_out, int* overflow_flag, void* stream);
 int bdetr_p16_unpack(const void* p, int is_f16, int64_t n, float* out, void* stream);
@@ -177,6 +179,18 @@ int bdetr_p16_conv2d_fwd(const void* x_f16, const void* w_f16, const float* bias
 /* dx fp32 [N,H,W,C] (+)= conv_transpose(dy_bf16 P16-bf16 [N,OH,OW,K], wt_bf16) */
 int bdetr_p16_conv2d_bwd_data(const void* dy_bf16, const void* wt_bf16, float* dx,
                               const bdetr_conv_desc* d, int accumulate, void* stream);
+/* The same product with the BatchNorm-backward REDUCTION of the layer that produced this conv's input fused into the
+ * epilogue: dx is the gradient of out = relu?(gamma * (y - mean) * rstd + beta) (no residual), and while the dx tile is
+ * stored its per-column partial sums of g = dx * [out > 0] and g * xhat are written to part_g / part_gx
+ * [bdetr_p16_conv2d_bwd_data_stat_chunks(d)][C] - the pass of bdetr_bn_bwd(_p16) that would re-read dx and y.  Hand
+ * them to bdetr_bn_bwd_p16 (pre_g / pre_gx / pre_n). */
+typedef struct {
+    const float* y; const float* mean; const float* rstd; const float* gamma; const float* beta; int relu;
+    float* part_g; float* part_gx;
+} bdetr_bn_bwd_fuse;
+int bdetr_p16_conv2d_bwd_data_stat_chunks(const bdetr_conv_desc* d);
+int bdetr_p16_conv2d_bwd_data_bnstats(const void* dy_bf16, const void* wt_bf16, float* dx,
+                                      const bdetr_conv_desc* d, const bdetr_bn_bwd_fuse* bn, void* stream);
 /* dw fp32 [K][R][S][C] += sum over pixels of dy x patches(x); with splitk > 1 the slices add with float
  * atomics, so dw must hold zeros (or the running sum) on entry */
 int bdetr_p16_conv2d_bwd_weight_splitk(const bdetr_conv_desc* d);

@@ -183,3 +183,26 @@ def test_bn_p16_producers_match_the_fp32_kernels(cuda, rows, C, relu, res):
             dxb4, dx34, dg4, db4, dres4 = k.bn_bwd_p16(dout, bits_, xd, mean, rstd, gamma, relu, False, want_residual_grad=True, beta=beta,
                                                        want_fp32=True, out_p16=2)
             assert torch.equal(dx34, dx) and torch.equal(dres4, dres) and torch.equal(dg4, dg) and torch.equal(db4, db)
+
+
+@pytest.mark.parametrize("N,H,W,C,K,R,relu", [(2, 20, 20, 64, 256, 1, True), (4, 40, 40, 256, 256, 3, True), (3, 9, 11, 128, 64, 3, False), (16, 40, 40, 256, 1024, 1, True)])
+def test_bn_backward_reduction_fused_into_the_bwd_data_epilogue(cuda, N, H, W, C, K, R, relu):
+    """bdetr_p16_conv2d_bwd_data_bnstats: the backward-data product of conv l+1 also emits the BatchNorm-backward partial sums of
+    layer l (whose output fed the conv).  dx is bit-identical to the plain launch, and bn_bwd_p16 fed with the partials gives the
+    dgamma / dbeta / dx of the two-pass form (same arithmetic, different summation order: 1e-5)."""
+    from boosted_detr_amd import kernels as k
+    g = k.ConvGeom(N, H, W, C, K, R, R, 1, R // 2)
+    rows = N * H * W
+    y_prev = dev(rnd(rows, C, seed=1) * 2 + 0.3)                      # layer l's conv output
+    gamma, beta = dev(1 + 0.1 * rnd(C, seed=2)), dev(0.1 * rnd(C, seed=3))
+    mean, rstd = k.bn_stats(rows, C, k.colstats(y_prev), 1.001e-5, 0.99, True, dev(torch.zeros(C)), dev(torch.ones(C)), like=y_prev)
+    w = rnd(K, R, R, C, seed=4, scale=(R * R * C) ** -0.5)
+    _, wt = k.p16_pack_conv_weights(dev(w), want_fwd=False)
+    _, dyb = k.p16_pack(dev(rnd(N, g.OH, g.OW, K, seed=5)), want_f16=False)
+    dx_plain = k.p16_conv2d_bwd_data(dyb, wt, g)
+    dx, parts = k.p16_conv2d_bwd_data_bnstats(dyb, wt, g, y_prev, mean, rstd, gamma, beta, relu)
+    assert torch.equal(dx, dx_plain)
+    ref = k.bn_bwd_p16(dx.view(rows, C), None, y_prev, mean, rstd, gamma, relu, False, beta=beta, want_fp32=True)
+    got = k.bn_bwd_p16(dx.view(rows, C), None, y_prev, mean, rstd, gamma, relu, False, beta=beta, want_fp32=True, pre=parts)
+    close(got[2], ref[2], rtol=1e-5); close(got[3], ref[3], rtol=1e-5)          # dgamma, dbeta
+    close(got[1], ref[1], rtol=1e-5)                                             # dx of the BatchNorm
