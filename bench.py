@@ -113,6 +113,47 @@ def hbm_traffic_per_launch():
     return None
 
 
+PEAK_HBM_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E 8 TB/s (6.3 TB/s measured for a float4 copy)
+
+
+def roofline_by_class(L, steps):
+    """The conv/GEMM launches of the bracketed region by operand class, each against BOTH roofs: algorithmic TFLOP/s vs the
+    3-product MFMA roof and algorithmic bytes (every operand and the output touched once, 4 bytes per element) per second vs
+    the HBM roof.  An im2col (3x3 / 7x7) launch reads its input tensor once, not once per tap."""
+    import csv
+    import tempfile
+    with tempfile.NamedTemporaryFile("r", suffix=".csv") as f:
+        L.bdetr_prof_dump(f.name.encode())
+        rows = list(csv.DictReader(open(f.name)))
+    classes = {}
+    for r in rows:
+        I, J, R, kind, ms = int(r["I"]), int(r["J"]), int(r["R"]), int(r["kind"]), float(r["ms"])
+        if ms <= 0:
+            continue
+        arith, lk = kind // 10000, kind % 10000
+        if arith >= 3:                           # sgemm.hip: 0 dense, 1000 patch rows, 2000 dense wgrad, 3000 patch-column wgrad
+            a_patch, b_patch = lk == 1000, lk == 3000
+        else:                                    # igemm.hip: LoaderId<LA> * 1000 + A_RC * 100 + LoaderId<LB> * 10 + B_RC, patch loader id 1
+            a_patch, b_patch = lk // 1000 == 1, lk // 10 % 10 == 1
+        patch = a_patch or b_patch
+        dim = R if a_patch else J
+        taps = (49 if dim % 49 == 0 else 9 if dim % 9 == 0 else 1) if patch else 1
+        # operand A [I x R], operand B [J x R], output [I x J]; the patch operand is the input tensor, read once (stride-1 count)
+        mult = max(1, round(float(r["gflop"]) * 1e9 / (2.0 * I * J * R)))      # batched launches (attention heads)
+        nbytes = 4.0 * mult * (I * R / (taps if a_patch else 1) + J * R / (taps if b_patch else 1) + I * J)
+        name = ("im2col 3x3 / 7x7 convolutions" if patch else "1x1 convolutions and Dense layers") + (" on pre-split operands" if arith >= 3 else " (in-kernel split / fp32)")
+        c = classes.setdefault(name, [0, 0.0, 0.0, 0.0])
+        c[0] += 1; c[1] += ms; c[2] += float(r["gflop"]); c[3] += nbytes
+    out = {}
+    for name, (n, ms, gf, nb) in classes.items():
+        tf, gbs = gf / ms, nb / ms / 1e6
+        out[name] = {"launches_per_step": n // steps, "kernel_ms_per_step": round(ms / steps, 3), "tflops": round(tf, 1),
+                     "frac_of_mfma_roof": round(tf / (PEAK_16BIT_MFMA_TFLOPS / 3), 3), "algorithmic_gb_per_s": round(gbs, 0),
+                     "frac_of_hbm_roof": round(gbs / PEAK_HBM_GBS, 3),
+                     "bound": "mfma" if tf / (PEAK_16BIT_MFMA_TFLOPS / 3) >= gbs / PEAK_HBM_GBS else "hbm"}
+    return out
+
+
 def dtype_note(model) -> str:
     from boosted_detr_amd import kernels as K
     mode = model.train_gemm_precision or K.get_gemm_precision()
@@ -279,6 +320,7 @@ def main():
         _lib.check(L.bdetr_prof_read(ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)), "prof_read")
         if os.environ.get("BDETR_PROF_DUMP"):
             L.bdetr_prof_dump(os.environ["BDETR_PROF_DUMP"].encode())
+        by_class = roofline_by_class(L, args.steps)
         by_arith, peak_ms = {}, 0.0
         for code, (label, peak) in ARITH.items():
             m_, n_, f_ = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
@@ -300,6 +342,10 @@ def main():
                     "kernel": "igemm_kernel + sgemm_kernel (MFMA implicit-GEMM family: conv fwd/bwd-data/bwd-weight, dense; algorithmic FLOPs = 2*I*J*R)",
                     "peak_note": "FLOP-weighted harmonic mean of the per-arithmetic peaks in by_arithmetic (fp32 MFMA 157.3; split = 2500/3)",
                     "by_arithmetic": by_arith,
+                    "by_class": by_class,
+                    "by_class_note": "each class against both roofs (3-product MFMA roof 833 TFLOP/s; HBM 8 TB/s with every operand and the "
+                                     "output counted once at 4 bytes per element): the 1x1 layers and the Dense layers are bandwidth / launch "
+                                     "bound, the im2col layers MFMA bound",
                     "launches_per_step": n.value // args.steps, "avg_launch_us": round(ms.value * 1e3 / n.value, 2),
                     "avg_launch_gflop": round(fl.value / n.value / 1e9, 3),
                     "kernel_ms_per_step": round(ms.value / args.steps, 3), "gflop_per_step": round(fl.value / args.steps / 1e9, 1),
