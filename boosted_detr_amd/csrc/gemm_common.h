@@ -5,6 +5,7 @@
 // f32x16 accumulators and share the problem description, the epilogue and the live-profiling hooks.
 #pragma once
 #include "common.h"
+#include <type_traits>
 
 namespace bdgemm {
 
@@ -33,6 +34,7 @@ struct GemmParams {
     // that would re-read C and y (colreduce2<BnBwdFn>) disappears.  bnb_y has C's shape and leading dimension.
     const float* bnb_y; const float* bnb_mean; const float* bnb_rstd; const float* bnb_gamma; const float* bnb_beta;
     int bnb_relu; float* bnb_sum_g; float* bnb_sum_gx;
+    int dbg;
 };
 
 inline void init_params(GemmParams& g) {
@@ -53,15 +55,74 @@ __device__ __forceinline__ int xcd_tile(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// First half of every epilogue, in registers: bias + activation, then per-column partial sums of the output
+// (BatchNorm statistics ride the conv epilogue).  The activation is a compile-time constant of each copy of the loop
+// nest: a run-time switch per element compiled to a chain of scalar branches per accumulator register (64 of them per
+// lane on a 128x128 tile - about 3 us per workgroup with nothing else going on).
+// bias_pre (may be null): the tile's bias values, one per 32-column block of this wave, loaded by the caller before its K
+// loop so that the epilogue does not start with an exposed memory round trip (gemm_load_bias).
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void gemm_load_bias(const GemmParams& g, int j0, float (&bias_pre)[BN / WN / 32]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wn = wave % WN;
+#pragma unroll
+    for (int b = 0; b < BN / WN / 32; ++b) {
+        const int j = j0 + wn * (BN / WN) + b * 32 + (lane & 31);
+        bias_pre[b] = (g.bias != nullptr && j < g.J) ? g.bias[j] : 0.f;
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void gemm_bias_act_stats(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], const GemmParams& g, int tile_i, int i0, int j0,
+                                                    const float* bias_pre = nullptr) {
+    constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));          // recompute the lane-derived indices here (see sgemm.hip's direct_epilogue)
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN, li = lane & 31, lh = lane >> 5;
+    auto bias_act_stats = [&](auto act_c) {
+        constexpr int ACT = decltype(act_c)::value;
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int j = j0 + wn * WTN + b * 32 + li;
+            const bool jok = j < g.J;
+            const float bias = bias_pre != nullptr ? bias_pre[b] : ((g.bias != nullptr && jok) ? g.bias[j] : 0.f);
+            float csum = 0.f, csq = 0.f;
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int i = i0 + wm * WTM + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    const float v = apply_act(g.alpha * acc[a][b][e] + bias, ACT);
+                    acc[a][b][e] = v;
+                    const float vs = (i < g.I && jok) ? v : 0.f;
+                    csum += vs; csq += vs * vs;
+                }
+            }
+            if (g.stat_sum != nullptr) {
+                csum += __shfl_xor(csum, 32, 64);
+                csq += __shfl_xor(csq, 32, 64);
+                if (lh == 0 && jok) {
+                    const int64_t chunk = (int64_t)tile_i * WM + wm;
+                    g.stat_sum[chunk * g.J + j] = csum;
+                    g.stat_sq[chunk * g.J + j] = csq;
+                }
+            }
+        }
+    };
+    if (g.act == BDETR_ACT_NONE) {
+        if (g.bias != nullptr || g.alpha != 1.f || g.stat_sum != nullptr) bias_act_stats(std::integral_constant<int, BDETR_ACT_NONE>{});
+    } else if (g.act == BDETR_ACT_RELU) bias_act_stats(std::integral_constant<int, BDETR_ACT_RELU>{});
+    else bias_act_stats(std::integral_constant<int, BDETR_ACT_TANH>{});
+}
+
 // Epilogue of a BM x BN workgroup tile held as TM x TN 32x32 accumulators per wave (C/D layout of the
-// 32x32 MFMAs: column = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)): bias + activation,
-// per-column partial sums of the output (BatchNorm statistics ride the conv epilogue), then either
-// LDS-transposed 16-byte row stores (store / accumulate) or per-element stores / atomics (split-K).
-// `lds` must hold LDS_FLOATS >= BM * BN floats and be free to overwrite once every wave has passed the
-// barrier this function starts with.
+// 32x32 MFMAs: column = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)): bias + activation and the
+// statistics (above), then either LDS-transposed 16-byte row stores (store / accumulate) or per-element stores /
+// atomics (split-K).  `lds` must hold LDS_FLOATS >= BM * BN floats and be free to overwrite once every wave has
+// passed the barrier this function starts with.
 template <int BM, int BN, int WM, int WN, int NT, int LDS_FLOATS>
 __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], const GemmParams& g, float* lds,
-                                              int tile_i, int i0, int j0, float* cbase) {
+                                              int tile_i, int i0, int j0, float* cbase, const float* bias_pre = nullptr) {
     constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN, li = lane & 31, lh = lane >> 5;
@@ -71,40 +132,18 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
         int oh = rem / g.rm_OW; int ow = rem - oh * g.rm_OW;
         return ((int64_t)n * g.rm_H + (int64_t)oh * g.rm_stride) * g.rm_W + (int64_t)ow * g.rm_stride;
     };
-    // bias + activation in registers, BN partial statistics from registers
-#pragma unroll
-    for (int b = 0; b < TN; ++b) {
-        const int j = j0 + wn * WTN + b * 32 + li;
-        const bool jok = j < g.J;
-        const float bias = (g.bias != nullptr && jok) ? g.bias[j] : 0.f;
-        float csum = 0.f, csq = 0.f;
-#pragma unroll
-        for (int a = 0; a < TM; ++a) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int i = i0 + wm * WTM + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                const float v = apply_act(g.alpha * acc[a][b][e] + bias, g.act);
-                acc[a][b][e] = v;
-                if (i < g.I && jok) { csum += v; csq += v * v; }
-            }
-        }
-        if (g.stat_sum != nullptr) {
-            csum += __shfl_xor(csum, 32, 64);
-            csq += __shfl_xor(csq, 32, 64);
-            if (lh == 0 && jok) {
-                const int64_t chunk = (int64_t)tile_i * WM + wm;
-                g.stat_sum[chunk * g.J + j] = csum;
-                g.stat_sq[chunk * g.J + j] = csq;
-            }
-        }
-    }
+    gemm_bias_act_stats<BM, BN, WM, WN>(acc, g, tile_i, i0, j0, bias_pre);
 
     if (g.vec_store && g.mode != ST_ATOMIC) {
         // Transpose the tile through LDS (the staging buffers are free once every wave is past the barrier) so
         // that every lane stores 16 contiguous bytes: whole rows per 16 lanes instead of 4-byte stores in 128-byte
         // segments - 4x fewer store instructions, full-line writes.
-        constexpr int CLD = (BM * (BN + 4) <= LDS_FLOATS) ? BN + 4 : BN;
+        constexpr bool PAD = BM * (BN + 4) <= LDS_FLOATS;
+        constexpr int CLD = PAD ? BN + 4 : BN;
         static_assert(BM * CLD <= LDS_FLOATS, "epilogue tile must fit in the staging LDS");
+        // Without room for the row padding the two half-waves of an accumulator register (rows r and r + 4) would hit the
+        // same 32 banks: XOR bit 5 of the column with bit 2 of the row instead (64 banks x 4 B).
+        constexpr bool SWZ = !PAD && BN % 64 == 0;
         __syncthreads();
 #pragma unroll
         for (int a = 0; a < TM; ++a)
@@ -112,77 +151,109 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
             for (int b = 0; b < TN; ++b)
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
-                    lds[(wm * WTM + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * CLD + wn * WTN + b * 32 + li] = acc[a][b][e];
+                    lds[(wm * WTM + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * CLD + ((wn * WTN + b * 32 + li) ^ (SWZ ? lh << 5 : 0))] = acc[a][b][e];
         __syncthreads();
-        constexpr int V_PER_ROW = BN / 4;
-        static_assert(NT % V_PER_ROW == 0, "a thread keeps one column group");
-        const bool bnb = g.bnb_y != nullptr;
-        const int jc = j0 + 4 * (tid % V_PER_ROW);               // this thread's 4 columns (the same in every iteration)
-        f32x4 bm = {0, 0, 0, 0}, brs = bm, bgm = bm, bbt = bm, sg = bm, sgx = bm;
-        if (bnb && jc < g.J) {
-            bm = *reinterpret_cast<const f32x4*>(g.bnb_mean + jc); brs = *reinterpret_cast<const f32x4*>(g.bnb_rstd + jc);
-            bgm = *reinterpret_cast<const f32x4*>(g.bnb_gamma + jc); bbt = *reinterpret_cast<const f32x4*>(g.bnb_beta + jc);
-        }
+        constexpr int V_PER_ROW = BN / 4, RSTEP = NT / V_PER_ROW, ITERS = BM / RSTEP;
+        static_assert(NT % V_PER_ROW == 0 && BM % RSTEP == 0, "a thread keeps one column group and a fixed row stride");
+        static_assert(!SWZ || RSTEP % 8 == 0, "the swizzle bit of a thread's rows must not change between iterations");
+        const int c4 = tid % V_PER_ROW, r0 = tid / V_PER_ROW;
+        const int jc = j0 + 4 * c4;                              // this thread's 4 columns (the same in every iteration)
+        const bool jok = jc < g.J;
+        const float* lrow = lds + r0 * CLD + ((4 * c4) ^ (SWZ ? ((r0 >> 2) & 1) << 5 : 0));
+        // Every uniform switch (row map, accumulate, fused BatchNorm-backward sums) selects a fully unrolled copy of the
+        // loop: all LDS reads, then all global loads, then the stores - one memory round trip per tile instead of one
+        // per row group (the run-time switches inside a rolled loop waited on every load and store in turn).
+        auto vec_out = [&](auto rowmap_c, auto accum_c, auto bnb_c) {
+            constexpr bool ROWMAP = decltype(rowmap_c)::value, ACCUM = decltype(accum_c)::value, BNB = decltype(bnb_c)::value;
+            f32x4 val[ITERS], old[ACCUM ? ITERS : 1], yv[BNB ? ITERS : 1];
+            float* dst[ITERS];
+            bool ok[ITERS];
 #pragma unroll
-        for (int v = tid; v < BM * V_PER_ROW; v += NT) {
-            const int r = v / V_PER_ROW, c4 = v - r * V_PER_ROW;
-            const int i = i0 + r, j = j0 + 4 * c4;
-            if (i < g.I && j < g.J) {
-                f32x4 val = *reinterpret_cast<const f32x4*>(lds + r * CLD + 4 * c4);
-                f32x4* dst = reinterpret_cast<f32x4*>(cbase + out_row(i) * g.ldc + j);
-                if (g.mode == ST_ACCUM) val += *dst;
-                *dst = val;
-                if (bnb) {
-                    const f32x4 yv = *reinterpret_cast<const f32x4*>(g.bnb_y + (int64_t)i * g.ldc + j);
+            for (int it = 0; it < ITERS; ++it) val[it] = *reinterpret_cast<const f32x4*>(lrow + it * RSTEP * CLD);
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                const int i = i0 + r0 + it * RSTEP;
+                ok[it] = jok && i < g.I;
+                int64_t row = i;
+                if constexpr (ROWMAP) row = out_row(i);
+                dst[it] = cbase + row * g.ldc + jc;
+                if constexpr (ACCUM) { old[it] = f32x4{0, 0, 0, 0}; if (ok[it]) old[it] = *reinterpret_cast<const f32x4*>(dst[it]); }
+                if constexpr (BNB) { yv[it] = f32x4{0, 0, 0, 0}; if (ok[it]) yv[it] = *reinterpret_cast<const f32x4*>(g.bnb_y + (int64_t)i * g.ldc + jc); }
+            }
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                if constexpr (ACCUM) val[it] += old[it];
+                if ((g.dbg & 1) && val[it][0] != 1234567.f) continue;
+                if (ok[it]) *reinterpret_cast<f32x4*>(dst[it]) = val[it];
+            }
+            if constexpr (BNB) {
+                f32x4 bm = {0, 0, 0, 0}, brs = bm, bgm = bm, bbt = bm, sg = bm, sgx = bm;
+                if (jok) {
+                    bm = *reinterpret_cast<const f32x4*>(g.bnb_mean + jc); brs = *reinterpret_cast<const f32x4*>(g.bnb_rstd + jc);
+                    bgm = *reinterpret_cast<const f32x4*>(g.bnb_gamma + jc); bbt = *reinterpret_cast<const f32x4*>(g.bnb_beta + jc);
+                }
+#pragma unroll
+                for (int it = 0; it < ITERS; ++it) {
+                    if (!ok[it]) continue;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const bool on = !g.bnb_relu || (__builtin_fmaf(yv[e] - bm[e], brs[e] * bgm[e], bbt[e]) > 0.f);      // = norm.hip's bn_affine
-                        const float ge = on ? val[e] : 0.f;
-                        sg[e] += ge; sgx[e] += ge * ((yv[e] - bm[e]) * brs[e]);
+                        const bool on = !g.bnb_relu || (__builtin_fmaf(yv[it][e] - bm[e], brs[e] * bgm[e], bbt[e]) > 0.f);      // = norm.hip's bn_affine
+                        const float ge = on ? val[it][e] : 0.f;
+                        sg[e] += ge; sgx[e] += ge * ((yv[it][e] - bm[e]) * brs[e]);
+                    }
+                }
+                // fold the NT / V_PER_ROW threads that share a column group (fixed order), one partial row per tile_i
+                static_assert(NT * 8 <= LDS_FLOATS, "reduction scratch must fit");
+                __syncthreads();                                      // every thread is done reading the C tile
+                *reinterpret_cast<f32x4*>(lds + tid * 8) = sg;
+                *reinterpret_cast<f32x4*>(lds + tid * 8 + 4) = sgx;
+                __syncthreads();
+                if (tid < V_PER_ROW && jok) {
+                    f32x4 a = {0, 0, 0, 0}, b = a;
+#pragma unroll
+                    for (int k = 0; k < RSTEP; ++k) {
+                        a += *reinterpret_cast<const f32x4*>(lds + (tid + k * V_PER_ROW) * 8);
+                        b += *reinterpret_cast<const f32x4*>(lds + (tid + k * V_PER_ROW) * 8 + 4);
+                    }
+                    *reinterpret_cast<f32x4*>(g.bnb_sum_g + (int64_t)tile_i * g.J + jc) = a;
+                    *reinterpret_cast<f32x4*>(g.bnb_sum_gx + (int64_t)tile_i * g.J + jc) = b;
+                }
+            }
+        };
+        using T = std::true_type; using F = std::false_type;
+        const bool accum = g.mode == ST_ACCUM;
+        if (g.bnb_y != nullptr) vec_out(F{}, F{}, T{});                      // host contract: plain store, no row map
+        else if (g.rowmap) { if (accum) vec_out(T{}, T{}, F{}); else vec_out(T{}, F{}, F{}); }
+        else if (accum) vec_out(F{}, T{}, F{});
+        else vec_out(F{}, F{}, F{});
+        return;
+    }
+    // per-element stores / accumulates / atomics (split-K, or rows that are not 16-byte aligned): the mode is hoisted too
+    auto scalar_out = [&](auto mode_c) {
+        constexpr int MODE = decltype(mode_c)::value;
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int j = j0 + wn * WTN + b * 32 + li;
+            if (j >= g.J) continue;
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int i = i0 + wm * WTM + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    if (i < g.I) {
+                        float* dst = cbase + out_row(i) * g.ldc + j;
+                        const float v = acc[a][b][e];
+                        if constexpr (MODE == ST_STORE) *dst = v;
+                        else if constexpr (MODE == ST_ACCUM) *dst += v;
+                        else atomicAdd(dst, v);
                     }
                 }
             }
         }
-        if (bnb) {
-            // fold the NT / V_PER_ROW threads that share a column group (fixed order), one partial row per tile_i
-            constexpr int G = NT / V_PER_ROW;
-            static_assert(NT * 8 <= LDS_FLOATS, "reduction scratch must fit");
-            __syncthreads();                                      // every thread is done reading the C tile
-            *reinterpret_cast<f32x4*>(lds + tid * 8) = sg;
-            *reinterpret_cast<f32x4*>(lds + tid * 8 + 4) = sgx;
-            __syncthreads();
-            if (tid < V_PER_ROW && jc < g.J) {
-                f32x4 a = {0, 0, 0, 0}, b = a;
-#pragma unroll
-                for (int k = 0; k < G; ++k) {
-                    a += *reinterpret_cast<const f32x4*>(lds + (tid + k * V_PER_ROW) * 8);
-                    b += *reinterpret_cast<const f32x4*>(lds + (tid + k * V_PER_ROW) * 8 + 4);
-                }
-                *reinterpret_cast<f32x4*>(g.bnb_sum_g + (int64_t)tile_i * g.J + jc) = a;
-                *reinterpret_cast<f32x4*>(g.bnb_sum_gx + (int64_t)tile_i * g.J + jc) = b;
-            }
-        }
-        return;
-    }
-#pragma unroll
-    for (int b = 0; b < TN; ++b) {
-        const int j = j0 + wn * WTN + b * 32 + li;
-        if (j >= g.J) continue;
-#pragma unroll
-        for (int a = 0; a < TM; ++a) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int i = i0 + wm * WTM + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (i < g.I) {
-                    float* dst = cbase + out_row(i) * g.ldc + j;
-                    const float v = acc[a][b][e];
-                    if (g.mode == ST_STORE) *dst = v;
-                    else if (g.mode == ST_ACCUM) *dst += v;
-                    else atomicAdd(dst, v);
-                }
-            }
-        }
-    }
+    };
+    if (g.mode == ST_STORE) scalar_out(std::integral_constant<int, ST_STORE>{});
+    else if (g.mode == ST_ACCUM) scalar_out(std::integral_constant<int, ST_ACCUM>{});
+    else scalar_out(std::integral_constant<int, ST_ATOMIC>{});
 }
 
 // ---- host side, defined in igemm.hip ----

@@ -39,11 +39,11 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
 
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned records = NUM_RECORDS) {
     const unsigned long long a = reinterpret_cast<unsigned long long>(p);
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
     void* q = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
-    return __builtin_amdgcn_make_buffer_rsrc(q, 0, (int)NUM_RECORDS, 0x00020000);
+    return __builtin_amdgcn_make_buffer_rsrc(q, 0, (int)__builtin_amdgcn_readfirstlane((int)records), 0x00020000);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -63,46 +63,57 @@ struct PPatch {
 // may "underflow" but are only used when the bounds test passed.
 //
 // ---- RR: the reduction index is the contiguous one; a lane loads 16 bytes = 8 r of one half of ONE row ----
+// A lane fetches the same 16-byte chunk q of its row's 128-byte K-step segment in every load of a stage (q >> 1 = which
+// 8 r, q & 1 = hi / lo; see the LDS image below), so q is folded into the row's byte offset once per tile.
 struct RRDense {
     using Op = PDense;
     using Col = int;                                          // (XX-mode state: unused)
-    struct Row { unsigned off; bool ok; };
+    // Rows past the end of the matrix lie beyond the buffer descriptor (num_records = rows * ld * 4): no flag
+    struct Row { unsigned off; };
     struct Step {};                                           // per-K-step uniform state: none
-    static __device__ __forceinline__ Row row(const Op& op, int r, int lim) { Row c; c.ok = r < lim; c.off = (unsigned)r * op.ld * 4u; return c; }
+    static __device__ __forceinline__ unsigned records(const Op& op) { return (unsigned)op.rows * op.ld * 4u; }
+    static __device__ __forceinline__ Row row(const Op& op, int r, int q) { Row c; c.off = (unsigned)r * op.ld * 4u + 16u * (unsigned)q; return c; }
     static __device__ __forceinline__ Step step_init(const Op&, int) { return {}; }
     static __device__ __forceinline__ void step_next(const Op&, Step&) {}
-    // q = 16-byte chunk inside the step's 128-byte row segment (q >> 1 = which 8 r, q & 1 = hi / lo)
-    static __device__ __forceinline__ unsigned voff(const Op& op, const Row& c, const Step&, int r0, int q, int r_lim) {
-        return (c.ok && r0 + 8 * (q >> 1) < r_lim) ? c.off + (unsigned)r0 * 4u + 16u * (unsigned)q : OOB;
+    // klim = r_lim - 8 * (q >> 1): the chunk's first r must stay below it (the last K-step of a row may be partial)
+    static __device__ __forceinline__ unsigned voff(const Op&, const Row& c, const Step&, int r0, int klim) {
+        return r0 < klim ? c.off + (unsigned)r0 * 4u : OOB;
     }
 };
 struct RRPatch {
     using Op = PPatch;
     using Col = int;
-    // base = byte offset of the row's tap-(0,0) input pixel; the K-step's tap / channel offset is uniform (Step), so an
-    // address is base + tapoff + 16 q: no per-load multiplies
-    struct Row { unsigned base; int ih0, iw0; bool ok; };
-    struct Step { int tr, ts, c0; unsigned tapoff; };         // tap (row, col), first channel of the K-step (C % 32 == 0), their byte offset
-    static __device__ __forceinline__ Row row(const Op& op, int r, int lim) {
-        Row c; c.ok = r < lim;
+    // base = byte offset of the row's tap-(0,0) input pixel plus the lane's chunk; mask bit (tr * S + ts) = that tap's input
+    // pixel is inside the image (all clear for rows past the end).  The K-step's tap is uniform (Step), so an address
+    // costs an and, a compare, an add and a select: no per-load index arithmetic.  C % 32 == 0: a K-step never straddles
+    // taps or the end of the reduction.
+    struct Row { unsigned base, mask; };
+    struct Step { int tr, ts, c0; unsigned tapoff, tapbit; }; // tap (row, col), first channel of the K-step, their byte offset, the tap's mask bit
+    static __device__ __forceinline__ unsigned records(const Op&) { return NUM_RECORDS; }
+    static __device__ __forceinline__ Row row(const Op& op, int r, int q) {
+        Row c;
         const int ohw = op.OH * op.OW;
         const int n = r / ohw, rem = r - n * ohw, oh = rem / op.OW, ow = rem - oh * op.OW;
-        c.ih0 = oh * op.stride - op.pad; c.iw0 = ow * op.stride - op.pad;
-        c.base = ((unsigned)(n * op.H * op.W) + (unsigned)(c.ih0 * op.W + c.iw0)) * (unsigned)op.C * 4u;
+        const int ih0 = oh * op.stride - op.pad, iw0 = ow * op.stride - op.pad;
+        c.base = ((unsigned)(n * op.H * op.W) + (unsigned)(ih0 * op.W + iw0)) * (unsigned)op.C * 4u + 16u * (unsigned)q;
+        c.mask = 0;
+        if (r < op.rows) {
+            unsigned colbits = 0;
+            for (int ts = 0; ts < op.S; ++ts) colbits |= ((unsigned)(iw0 + ts) < (unsigned)op.W ? 1u : 0u) << ts;
+            for (int tr = 0; tr < op.R; ++tr) if ((unsigned)(ih0 + tr) < (unsigned)op.H) c.mask |= colbits << (tr * op.S);
+        }
         return c;
     }
     static __device__ __forceinline__ unsigned tap_bytes(const Op& op, const Step& s) { return ((unsigned)(s.tr * op.W + s.ts) * (unsigned)op.C + (unsigned)s.c0) * 4u; }
     static __device__ __forceinline__ Step step_init(const Op& op, int r0) {
-        Step s; const int tap = r0 / op.C; s.c0 = r0 - tap * op.C; s.tr = tap / op.S; s.ts = tap - s.tr * op.S; s.tapoff = tap_bytes(op, s); return s;
+        Step s; const int tap = r0 / op.C; s.c0 = r0 - tap * op.C; s.tr = tap / op.S; s.ts = tap - s.tr * op.S; s.tapoff = tap_bytes(op, s); s.tapbit = 1u << tap; return s;
     }
     static __device__ __forceinline__ void step_next(const Op& op, Step& s) {
         s.c0 += BK; s.tapoff += BK * 4u;
-        if (s.c0 >= op.C) { s.c0 = 0; if (++s.ts == op.S) { s.ts = 0; ++s.tr; } s.tapoff = tap_bytes(op, s); }
+        if (s.c0 >= op.C) { s.c0 = 0; s.tapbit <<= 1; if (++s.ts == op.S) { s.ts = 0; ++s.tr; } s.tapoff = tap_bytes(op, s); }
     }
-    static __device__ __forceinline__ unsigned voff(const Op& op, const Row& c, const Step& s, int r0, int q, int r_lim) {
-        const int ih = c.ih0 + s.tr, iw = c.iw0 + s.ts;
-        const bool ok = c.ok && r0 + 8 * (q >> 1) < r_lim && (unsigned)ih < (unsigned)op.H && (unsigned)iw < (unsigned)op.W;
-        return ok ? c.base + s.tapoff + 16u * (unsigned)q : OOB;
+    static __device__ __forceinline__ unsigned voff(const Op&, const Row& c, const Step& s, int, int) {
+        return (c.mask & s.tapbit) ? c.base + s.tapoff : OOB;
     }
 };
 
@@ -111,6 +122,7 @@ struct RRPatch {
 struct XXDense {
     using Op = PDense;
     using Row = int; using Step = int;                        // (RR-mode state: unused)
+    static __device__ __forceinline__ unsigned records(const Op&) { return NUM_RECORDS; }
     struct Col { unsigned off; int r; bool ok; };             // running byte offset of (row r, the lane's chunk)
     static __device__ __forceinline__ Col col(const Op& op, int x0, int slot, int x_lim, int r_first) {
         Col c; c.ok = x0 + 8 * (slot >> 1) < x_lim; c.r = r_first;
@@ -122,6 +134,7 @@ struct XXDense {
 struct XXPatch {
     using Op = PPatch;
     using Row = int; using Step = int;
+    static __device__ __forceinline__ unsigned records(const Op&) { return NUM_RECORDS; }
     // (oh, ow) of the load's output pixel, (ih, iw) of the input pixel its tap reads, and the running byte offset of
     // that input pixel's channel chunk
     struct Col { int r, oh, ow, ih, iw; unsigned off; bool ok; };
@@ -165,6 +178,128 @@ __device__ __forceinline__ int xx_swz(int r) { return ((r & 1) << 3) | ((r >> 1)
 
 constexpr int lds_bytes_for(int bm, int bn, int ns) { return ns * (bm + bn) * 128 > bm * bn * 4 ? ns * (bm + bn) * 128 : bm * bn * 4; }
 
+// Epilogue of the persistent RR kernels: the C tile goes from the accumulators straight to memory, one dword per lane
+// (an accumulator register of a 32x32 MFMA block is two 128-byte row segments: full lines, the shape the guide measured at
+// the plain-store rate).  No LDS is involved, so the staging ring is free for the NEXT tile's first stages while this
+// runs.  The buffer descriptor covers exactly the tile's valid rows (rows past I are dropped by the buffer unit's range
+// check), a lane's column is valid or not for the whole tile (an invalid one starts 2 GB out of range), and the row
+// offset is one running VGPR: a store costs one add, and the second 32-column block rides the instruction's immediate.
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void direct_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], const GemmParams& g, int tile_i, int i0, int j0, const float* bias_pre) {
+    constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
+    constexpr unsigned FAR = 0x80000000u;                    // + any in-tile offset (< 2^31) stays out of range
+    gemm_bias_act_stats<BM, BN, WM, WN>(acc, g, tile_i, i0, j0, bias_pre);
+    // The thread index is laundered through an empty asm: everything derived from it here is then recomputed per tile
+    // (a handful of VALU ops) instead of being hoisted out of the persistent loop and held in VGPRs across the K loop,
+    // where the accumulators and fragments leave no room (the hoisted copies spilled to scratch).
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN, li = lane & 31, lh = lane >> 5;
+
+    const unsigned ldc4 = (unsigned)g.ldc * 4u;
+    const int rows_here = min(BM, g.I - i0);
+    const int jl = j0 + wn * WTN + li;                      // column of b = 0
+    auto tile_rsrc = [&](const float* base) {                // rows i0 .. i0 + rows_here - 1 of a [I][ldc] fp32 matrix
+        const unsigned long long p = reinterpret_cast<unsigned long long>(base) + (unsigned long long)i0 * ldc4;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p), hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
+                                                 __builtin_amdgcn_readfirstlane(rows_here * (int)ldc4), 0x00020000);
+    };
+    // byte offset of (row of (a = 0, e = 0), column of block b) inside the tile
+    unsigned vcol[TN];
+#pragma unroll
+    for (int b = 0; b < TN; ++b) vcol[b] = jl + b * 32 < g.J ? (unsigned)(wm * WTM + 4 * lh) * ldc4 + (unsigned)(jl + b * 32) * 4u : FAR;
+    // walk the rows of the accumulator layout: (e & 3) + 8 * (e >> 2) + 32 * a
+    auto for_rows = [&](auto&& f) {
+        unsigned ro = 0;
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { f(a, e, ro); ro += (e & 3) == 3 ? 5u * ldc4 : ldc4; }
+    };
+
+    if (g.rowmap) {
+        // strided scatter (1x1 stride-2 backward-data; 6 launches per step): lane l owns the row map of the wave's row l
+        const __amdgpu_buffer_rsrc_t rsC = make_rsrc(g.c);
+        const int i = i0 + wm * WTM + (lane % WTM);
+        const int n = i / g.rm_OHOW, rem = i - n * g.rm_OHOW, oh = rem / g.rm_OW, ow = rem - oh * g.rm_OW;
+        const unsigned rmap = i < g.I ? (unsigned)((n * g.rm_H + oh * g.rm_stride) * g.rm_W + ow * g.rm_stride) * ldc4 : OOB;
+        const bool accum = g.mode == ST_ACCUM;
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const unsigned ro = (unsigned)__shfl((int)rmap, a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh, 64);
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    const unsigned vo = (ro != OOB && jl + b * 32 < g.J) ? ro + (unsigned)(jl + b * 32) * 4u : OOB;
+                    float v = acc[a][b][e];
+                    if (accum) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsC, vo, 0, 0));
+                    if (!(g.dbg & 1)) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsC, vo, 0, 0);
+                }
+            }
+        return;
+    }
+
+    const __amdgpu_buffer_rsrc_t rsC = tile_rsrc(g.c);
+    if (g.mode == ST_ACCUM) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            float old[TN][16];
+            unsigned ro = (unsigned)(a * 32) * ldc4;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+#pragma unroll
+                for (int b = 0; b < TN; ++b) old[b][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsC, vcol[b] + ro, 0, 0));
+                ro += (e & 3) == 3 ? 5u * ldc4 : ldc4;
+            }
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[a][b][e] += old[b][e];
+        }
+    }
+    if (g.bnb_y != nullptr) {
+        // fused BatchNorm-backward sums of g = C * [y' > 0] and g * xhat per column, straight from the accumulator
+        // layout (a lane owns a column); one partial row per (tile_i, wm)
+        const __amdgpu_buffer_rsrc_t rsY = tile_rsrc(g.bnb_y);
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int j = jl + b * 32;
+            const bool jok = j < g.J;
+            const float bm = jok ? g.bnb_mean[j] : 0.f, brs = jok ? g.bnb_rstd[j] : 0.f, bgm = jok ? g.bnb_gamma[j] : 0.f, bbt = jok ? g.bnb_beta[j] : 0.f;
+            float yv[TM][16];
+            for_rows([&](int a, int e, unsigned ro) { yv[a][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsY, vcol[b] + ro, 0, 0)); });
+            float sg = 0.f, sgx = 0.f;
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const bool in = wm * WTM + 4 * lh + a * 32 + (e & 3) + 8 * (e >> 2) < rows_here;
+                    const bool on = in && (!g.bnb_relu || (__builtin_fmaf(yv[a][e] - bm, brs * bgm, bbt) > 0.f));      // = norm.hip's bn_affine
+                    const float ge = on ? acc[a][b][e] : 0.f;
+                    sg += ge; sgx += ge * ((yv[a][e] - bm) * brs);
+                }
+            sg += __shfl_xor(sg, 32, 64);
+            sgx += __shfl_xor(sgx, 32, 64);
+            if (lh == 0 && jok) {
+                const int64_t chunk = (int64_t)tile_i * WM + wm;
+                g.bnb_sum_g[chunk * g.J + j] = sg;
+                g.bnb_sum_gx[chunk * g.J + j] = sgx;
+            }
+        }
+    }
+    if (g.dbg & 1) return;
+    for_rows([&](int a, int e, unsigned ro) {
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const float v = acc[a][b][e];           // (a scalar copy first: __builtin_bit_cast of a vector ELEMENT folds to element 0 on this hipcc)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsC, vcol[b] + ro, 0, 0);
+        }
+    });
+}
+
 // NS = LDS stages: the loads of K-step t + NS - 1 are issued while K-step t computes and a counted s_waitcnt
 // vmcnt leaves the younger stages in flight across the (raw) barrier.
 template <int BM, int BN, int WM, int WN, int NS, class LA, class LB, bool XX, bool F16>
@@ -191,35 +326,61 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
     // flattened launch order, and the tiles of one split-K slice read the same operand rows (the 9 taps of a 3x3
     // weight gradient, the row / column tiles of a 1x1 one).  Remapping the tiles of each slice alone spread a slice's
     // handful of tiles over all 8 L2s (measured: the 3x3 weight gradients fetched 13 GB per step for 1.4 GB of operands).
+    //
+    // The dense RR kernels (1x1 convolutions: short K, bound by the serial load -> MFMA -> store phases of a workgroup's
+    // life) are PERSISTENT: the grid is min(tiles, resident workgroups) and workgroup w walks the virtual block ids
+    // w, w + gridDim.x, ... (the same XCD every time: the resident count is a multiple of 8).  The patch kernels (3x3:
+    // MFMA-bound, measured equal or slower when persistent, and the f16 128x128 one does not fit its accumulators plus
+    // the loop-carried state in 256 VGPRs) and the XX kernels (split-K weight gradients) run one virtual block per
+    // workgroup.
+    constexpr bool PERSIST = !XX && std::is_same_v<LA, RRDense>;
+    static_assert(NS == 2, "both loops are written for a two-stage ring");
     const int nwg = g.tiles_i * g.tiles_j;
-    const int lin = xcd_tile(blockIdx.z * nwg + blockIdx.x, nwg * gridDim.z);
-    const int zz = lin / nwg, wg = lin - zz * nwg;
-    const int tile_i = wg / g.tiles_j, tile_j = wg - tile_i * g.tiles_j;
-    const int i0 = tile_i * BM, j0 = tile_j * BN;
+    const int total = PERSIST ? nwg : nwg * (int)gridDim.z;
+    int vb = PERSIST ? (int)blockIdx.x : (int)(blockIdx.z * nwg + blockIdx.x);
+    int tile_i, i0, j0, zz;
+    auto locate = [&](int v) {
+        const int lin = xcd_tile(v, total);
+        zz = lin / nwg;
+        const int wg = lin - zz * nwg;
+        tile_i = wg / g.tiles_j;
+        const int tile_j = wg - tile_i * g.tiles_j;
+        i0 = tile_i * BM; j0 = tile_j * BN;
+    };
+    locate(vb);
 
     int r_begin = 0, r_end = g.R;
     if (g.splitk > 1) { r_begin = zz * g.r_chunk; r_end = min(g.R, r_begin + g.r_chunk); }
 
-    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(opa.p);
-    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(opb.p);
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(opa.p, LA::records(opa));
+    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(opb.p, LB::records(opb));
 
     // ---------------- staging: HBM -> LDS, 16 bytes per lane, no registers ----------------
     typename LA::Row rowA[NIA]; typename LB::Row rowB[NIB]; typename LA::Col colA[NIA]; typename LB::Col colB[NIB];
-    int qA[NIA], qB[NIB], rrA[NIA], rrB[NIB];          // RR: source chunk;  XX: row inside the stage
-    if constexpr (!XX) {
+    int rrA[NIA], rrB[NIB];                            // XX: row inside the stage
+    // RR: the lane's source chunk.  Row x of the stage = (t * NW + wave) * 8 + (lane >> 3) is swizzled by (x >> 1) & 7 =
+    // ((t * NW + wave) & 1) * 4 + (lane >> 4), the same for every load t when NW is even
+    static_assert(XX || NW % 2 == 0, "one source chunk per lane needs an even wave count");
+    const int qsrc = (lane & 7) ^ (((wave & 1) << 2) | (lane >> 4));
+    const int klimA = min(r_end, (int)opa.cols) - 8 * (qsrc >> 1), klimB = min(r_end, (int)opb.cols) - 8 * (qsrc >> 1);      // (RR)
+    typename LA::Step stA; typename LB::Step stB;           // RR: per-K-step uniform state of the patch loaders (tap, first channel)
+    auto setup_rows = [&]() {                               // RR: the row descriptors of tile (i0, j0)
+        if constexpr (!XX) {
 #pragma unroll
-        for (int t = 0; t < NIA; ++t) {
-            const int x = (t * NW + wave) * 8 + (lane >> 3);
-            qA[t] = (lane & 7) ^ ((x >> 1) & 7);
-            rowA[t] = LA::row(opa, i0 + x, opa.rows);
-        }
+            for (int t = 0; t < NIA; ++t) {
+                const int x = (t * NW + wave) * 8 + (lane >> 3);
+                rowA[t] = LA::row(opa, i0 + x, qsrc);
+            }
 #pragma unroll
-        for (int t = 0; t < NIB; ++t) {
-            const int x = (t * NW + wave) * 8 + (lane >> 3);
-            qB[t] = (lane & 7) ^ ((x >> 1) & 7);
-            rowB[t] = LB::row(opb, j0 + x, opb.rows);
+            for (int t = 0; t < NIB; ++t) {
+                const int x = (t * NW + wave) * 8 + (lane >> 3);
+                rowB[t] = LB::row(opb, j0 + x, qsrc);
+            }
+            stA = LA::step_init(opa, r_begin); stB = LB::step_init(opb, r_begin);
         }
-    } else {
+    };
+    setup_rows();
+    if constexpr (XX) {
         constexpr int SA = BM / 4, SB = BN / 4;           // 16-byte slots per row
         static_assert(SA >= 16 && SB >= 16 && SA <= 64 && SB <= 64, "XX tiles: 64 <= BX <= 256");
 #pragma unroll
@@ -235,9 +396,6 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
             colB[t] = LB::col(opb, j0, (lane % SB) ^ xx_swz(r), opb.cols, r_begin + r);
         }
     }
-    // RR: per-K-step uniform state of the patch loaders (tap, first channel)
-    typename LA::Step stA; typename LB::Step stB;
-    if constexpr (!XX) { stA = LA::step_init(opa, r_begin); stB = LB::step_init(opb, r_begin); }
 
     // one 1-KiB wave-instruction of the stage (l < NIA: A tile, else B tile)
     auto issue_one = [&](int buf, int r0, auto l_c) {
@@ -246,13 +404,13 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
         if constexpr (l < NIA) {
             constexpr int t = l;
             unsigned vo;
-            if constexpr (!XX) vo = LA::voff(opa, rowA[t], stA, r0, qA[t], min(r_end, opa.cols));
+            if constexpr (!XX) vo = LA::voff(opa, rowA[t], stA, r0, klimA);
             else               vo = LA::voff(opa, colA[t], min(r_end, opa.rows));
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(sa + (t * NW + wave) * 1024), 16, (int)vo, 0, 0, 0);
         } else {
             constexpr int t = l - NIA;
             unsigned vo;
-            if constexpr (!XX) vo = LB::voff(opb, rowB[t], stB, r0, qB[t], min(r_end, opb.cols));
+            if constexpr (!XX) vo = LB::voff(opb, rowB[t], stB, r0, klimB);
             else               vo = LB::voff(opb, colB[t], min(r_end, opb.rows));
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void*)(sa + A_BYTES + (t * NW + wave) * 1024), 16, (int)vo, 0, 0, 0);
         }
@@ -272,18 +430,35 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
     // ---------------- accumulators ----------------
     constexpr int TM2 = F16 ? TM : 1, TN2 = F16 ? TN : 1;
     f32x16 acc[TM][TN], acc2[TM2][TN2];       // acc2: the 2^11-scaled cross products of the f16 pair
+    auto zero_acc = [&]() {
+        // an opaque zero: otherwise the persistent loop keeps whole zero-filled 16-register tuples alive across the K loop
+        // as the "constant" it re-initialises the accumulators from
+        float z = 0.f;
+        asm volatile("" : "+v"(z));
 #pragma unroll
-    for (int a = 0; a < TM; ++a)
+        for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < TN; ++b)
+            for (int b = 0; b < TN; ++b)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+                for (int e = 0; e < 16; ++e) acc[a][b][e] = z;
 #pragma unroll
-    for (int a = 0; a < TM2; ++a)
+        for (int a = 0; a < TM2; ++a)
 #pragma unroll
-        for (int b = 0; b < TN2; ++b)
+            for (int b = 0; b < TN2; ++b)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc2[a][b][e] = 0.f;
+                for (int e = 0; e < 16; ++e) acc2[a][b][e] = z;
+    };
+    auto fold_acc2 = [&]() {
+        if constexpr (F16) {
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[a][b][e] += acc2[a][b][e] * (1.f / LO_SCALE);
+        }
+    };
+    zero_acc();
 
     // ---------------- fragment reads + MFMAs of one stage ----------------
     auto frag_rr = [&](const unsigned char* tile, int x, int ks, u32x4& hi, u32x4& lo) {
@@ -352,34 +527,65 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
     };
 
     // ---------------- main loop ----------------
-    // One barrier per K-step.  Every wave issues exactly NLOAD loads per stage, in stage order, and the loop is
-    // branch-free (past the last K-step every lane's range check fails and the loads write zeros into an idle buffer),
-    // so "all but the youngest NLOAD * (NS - 2) of my loads are done" means "my share of stage kt has landed"; the
-    // barrier then extends that to every wave's share and also says that every wave is done reading stage kt - 1,
-    // whose buffer the loads issued right after it refill.  (Loads issued early - before the MFMAs, not between
-    // them - measured faster: they have the whole K-step to land.)
-    const int nk = (r_end - r_begin + BK - 1) / BK;
-#pragma unroll
-    for (int p = 0; p < NS - 1; ++p) issue_all(p, r_begin + p * BK);
-    int buf = 0, lbuf = NS - 1;
-    for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(NLOAD * (NS - 2)) : "memory");
-        issue_all(lbuf, r_begin + (kt + NS - 1) * BK);
-        kstep(buf);
-        buf = buf + 1 == NS ? 0 : buf + 1;
-        lbuf = lbuf + 1 == NS ? 0 : lbuf + 1;
+    if constexpr (PERSIST) {
+        // Two-stage ring, persistent over tiles.  Per K-step: wait for everything this wave has in flight (stage kt, and
+        // on a tile's first step the previous tile's C stores - on gfx9 stores count in vmcnt and return out of order with
+        // loads, so a counted wait cannot tell them apart), barrier (every wave's share of stage kt has landed and every
+        // wave is done reading stage kt - 1), refill the buffer stage kt - 1 used, compute.  After a tile's last K-step
+        // the NEXT tile's first two stages are issued into the (idle) ring BEFORE this tile's epilogue: the C stores
+        // and the next tile's first HBM round trip overlap instead of following each other (measured on the 64 -> 256
+        // channel 1x1 layer at 160x160: loads + MFMAs alone 76 us, stores alone 89 us, one after the other 141 us).
+        const int nk = (g.dbg & 2) ? 0 : (g.R + BK - 1) / BK;
+        auto prefetch = [&]() { if (nk > 0) issue_all(0, 0); if (nk > 1) issue_all(1, BK); };
+        prefetch();
+        for (;;) {
+            float bias_pre[TN];
+            gemm_load_bias<BM, BN, WM, WN>(g, j0, bias_pre);          // lands during the K loop
+            // (two K-steps per trip: the ring buffer is a compile-time constant of each half, so LDS addresses are
+            // lane bases + immediates instead of per-buffer copies held - and spilled - across the loop)
+            for (int kt = 0; kt < nk; kt += 2) {
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                if (kt >= 1 && kt + 1 < nk) issue_all(1, (kt + 1) * BK);
+                kstep(0);
+                if (kt + 1 < nk) {
+                    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                    if (kt + 2 < nk) issue_all(0, (kt + 2) * BK);
+                    kstep(1);
+                }
+            }
+            fold_acc2();
+            const int e_tile_i = tile_i, e_i0 = i0, e_j0 = j0;
+            const int nvb = vb + (int)gridDim.x;
+            const bool more = nvb < total;
+            if (more) { locate(nvb); setup_rows(); }
+            asm volatile("s_barrier" ::: "memory");                 // every wave is done reading the ring
+            if (more) prefetch();
+            direct_epilogue<BM, BN, WM, WN>(acc, g, e_tile_i, e_i0, e_j0, bias_pre);
+            if (!more) break;
+            vb = nvb;
+            zero_acc();
+        }
+    } else {
+        // One barrier per K-step: wait for my share of stage kt, barrier (every wave's share has landed and every wave
+        // is done reading stage kt - 1), refill that buffer with stage kt + 1, compute.  (Loads issued early - before the
+        // MFMAs, not between them - measured faster: they have the whole K-step to land.)
+        const int nk = (g.dbg & 2) ? 0 : (r_end - r_begin + BK - 1) / BK;
+        float bias_pre[TN];
+        gemm_load_bias<BM, BN, WM, WN>(g, j0, bias_pre);              // lands during the K loop
+        if (nk > 0) issue_all(0, r_begin);
+        for (int kt = 0; kt < nk; kt += 2) {
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            if (kt + 1 < nk) issue_all(1, r_begin + (kt + 1) * BK);
+            kstep(0);
+            if (kt + 1 < nk) {
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                if (kt + 2 < nk) issue_all(0, r_begin + (kt + 2) * BK);
+                kstep(1);
+            }
+        }
+        fold_acc2();
+        gemm_epilogue<BM, BN, WM, WN, NT, LDS_BYTES / 4>(acc, g, reinterpret_cast<float*>(lds), tile_i, i0, j0, g.c, bias_pre);
     }
-
-    // ---------------- epilogue ----------------
-    if constexpr (F16) {
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int b = 0; b < TN; ++b)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[a][b][e] += acc2[a][b][e] * (1.f / LO_SCALE);
-    }
-    gemm_epilogue<BM, BN, WM, WN, NT, LDS_BYTES / 4>(acc, g, reinterpret_cast<float*>(lds), tile_i, i0, j0, g.c);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -388,7 +594,10 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
 // Measured and not instantiated (tools/p16_bench.py over the ResNet-50 batch-16 layers, round 2): a 3-stage ring at
 // one 128x128 workgroup per CU (19.3 ms for all layers vs 15.3), 8-wave 256x128 tiles with 2 or 3 stages (17.3 / 17.4 ms;
 // equal on the MFMA-bound 3x3 layers, slower on the short-K 1x1 layers), next-stage loads interleaved between the MFMA
-// groups instead of issued up front (15.8 ms).  The template still takes NS and WM x WN.
+// groups instead of issued up front (15.8 ms), 3- and 4-stage rings at two workgroups per CU on 128x64 / 64x64 tiles for
+// the short-K 1x1 layers (equal or slower on every layer: those layers were bound by the serial load -> MFMA -> store
+// phases of a workgroup's life, which the persistent loop overlaps, not by bytes in flight).  The template still takes
+// NS and WM x WN.
 enum { T_128x128 = 0, T_128x64 = 1, T_64x64 = 2, T_COUNT = 3 };
 const int TILE_BM[T_COUNT] = {128, 128, 64};
 const int TILE_BN[T_COUNT] = {128, 64, 64};
@@ -424,9 +633,25 @@ int launch_cfg(const typename LA::Op& a, const typename LB::Op& b, GemmParams g,
     g.tiles_j = (int)cdiv64(g.J, BN);
     dim3 grid(g.tiles_i * g.tiles_j, 1, zdim);
     g.vec_store = (g.J % 4 == 0) && (g.ldc % 4 == 0) && aligned16(g.c);
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("BDETR_SGEMM_DBG"); dbg = e ? atoi(e) : 0; }
+    g.dbg = dbg;
+    if (dbg & 4) g.vec_store = 0;
     const bool prof = g_prof_on;
     if (prof) prof_begin(st, 2.0 * (double)g.I * (double)g.J * (double)g.R, g.I, g.J, g.R, zdim, BM, BN * 10 + NS,
                          (F16 ? AR_P16_F16 : AR_P16_BF16) * 10000 + kind);
+    if constexpr (!XX && std::is_same_v<LA, RRDense>) {
+        // persistent: as many workgroups as stay resident (a multiple of 8: one XCD per workgroup for all its tiles)
+        static int resident = 0;
+        if (resident == 0) {
+            int occ = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, sgemm_kernel<BM, BN, WM, WN, NS, LA, LB, XX, F16>, WM * WN * 64, 0) != hipSuccess || occ < 1) occ = 1;
+            resident = occ * num_cus() / 8 * 8;
+            if (resident < 8) resident = 8;
+        }
+        BDETR_CHECK_ARG(zdim == 1 && g.splitk == 1, "sgemm: the persistent kernels take no split-K / batch dimension");
+        if ((int)grid.x > resident) grid.x = resident;
+    }
     hipLaunchKernelGGL((sgemm_kernel<BM, BN, WM, WN, NS, LA, LB, XX, F16>), grid, dim3(WM * WN * 64), 0, st, a, b, g);
     if (prof) prof_end(st);
     return bdetr_launch_status("sgemm");
@@ -441,7 +666,9 @@ int launch_any(const typename LA::Op& a, const typename LB::Op& b, const GemmPar
     }
 }
 
-constexpr int64_t MAX_OPERAND_ELEMS = (int64_t)(NUM_RECORDS / 4) - 64;
+// 16 MB of slack: the row descriptors of a tile's rows past the end of a dense operand (up to 255 rows of at most 16,384
+// elements) must still lie beyond the buffer descriptor without wrapping the 32-bit offset
+constexpr int64_t MAX_OPERAND_ELEMS = (int64_t)(NUM_RECORDS / 4) - (4 << 20);
 bool span_ok(int64_t elems) { return elems >= 0 && elems <= MAX_OPERAND_ELEMS; }
 
 int check_conv(const bdetr_conv_desc* d, const char* who) {
@@ -452,6 +679,7 @@ int check_conv(const bdetr_conv_desc* d, const char* who) {
                     "%s: OH/OW inconsistent with geometry", who);
     BDETR_CHECK_ARG(d->C % 8 == 0 && d->K % 8 == 0, "%s: the P16 layout needs channel counts that are multiples of 8 (C=%d K=%d)", who, d->C, d->K);
     BDETR_CHECK_ARG((d->R == 1 && d->S == 1) || d->C % BK == 0, "%s: kernels larger than 1x1 need C %% %d == 0 (C=%d)", who, BK, d->C);
+    BDETR_CHECK_ARG(d->R * d->S <= 32 && (int64_t)d->R * d->S * d->C <= 16384 && d->C <= 16384 && d->K <= 16384, "%s: at most 32 taps and rows of at most 16,384 elements", who);
     BDETR_CHECK_ARG((int64_t)d->N * d->OH * d->OW < (1LL << 31) && (int64_t)d->R * d->S * d->C < (1LL << 31) && (int64_t)d->N * d->H * d->W < (1LL << 31),
                     "%s: problem too large", who);
     BDETR_CHECK_ARG(span_ok((int64_t)d->N * d->H * d->W * d->C) && span_ok((int64_t)d->N * d->OH * d->OW * d->K) && span_ok((int64_t)d->K * d->R * d->S * d->C),
@@ -478,6 +706,7 @@ extern "C" int bdetr_p16_supported(const bdetr_conv_desc* d) {
     if (!d || d->C % 8 || d->K % 8) return 0;
     if (!(d->R == 1 && d->S == 1) && d->C % BK) return 0;
     if (!(d->R == 1 && d->S == 1) && d->K % BK) return 0;          // backward-data gathers patches of dy: K plays C's role
+    if (d->R * d->S > 32 || (int64_t)d->R * d->S * d->C > 16384 || (int64_t)d->R * d->S * d->K > 16384) return 0;   // tap mask; row pitch bound
     if (d->stride > 1 && !(d->R == 1 && d->S == 1 && d->pad == 0)) return 0;
     return 1;
 }
@@ -520,7 +749,9 @@ static int bwd_data_tile(const bdetr_conv_desc* d) {
 extern "C" int bdetr_p16_conv2d_bwd_data_stat_chunks(const bdetr_conv_desc* d) {
     if (check_conv(d, "bdetr_p16_conv2d_bwd_data_stat_chunks")) return -1;
     const bool dense = d->R == 1 && d->S == 1 && d->pad == 0;
-    return (int)cdiv64(dense ? (int64_t)d->N * d->OH * d->OW : (int64_t)d->N * d->H * d->W, TILE_BM[bwd_data_tile(d)]);
+    const int t = bwd_data_tile(d);
+    // the persistent dense kernels write one partial row per (tile_i, wave row), the patch kernels one per tile_i
+    return (int)cdiv64(dense ? (int64_t)d->N * d->OH * d->OW : (int64_t)d->N * d->H * d->W, TILE_BM[t]) * (dense ? TILE_WM[t] : 1);
 }
 
 // dy_bf16: P16-bf16 [N,OH,OW,K]; wt_bf16: the transposed / tap-flipped P16-bf16 weight copy [C][R*S][K]
@@ -576,9 +807,10 @@ extern "C" int bdetr_p16_conv2d_bwd_data_bnstats(const void* dy_bf16, const void
 
 static int wgrad_tile(const bdetr_conv_desc* d) {
     const int64_t Kd = (int64_t)d->R * d->S * d->C;
-    if (!(d->K % 128 == 0 && Kd % 128 == 0)) return T_64x64;
     const int forced = forced_tile();
-    return (forced >= 0 && TILE_BN[forced] == 128 && (TILE_BM[forced] != 256 || d->K % 256 == 0)) ? forced : T_128x128;
+    if (forced >= 0 && d->K % TILE_BM[forced] == 0 && Kd % TILE_BN[forced] == 0) return forced;
+    if (!(d->K % 128 == 0 && Kd % 128 == 0)) return T_64x64;
+    return T_128x128;
 }
 
 extern "C" int bdetr_p16_conv2d_bwd_weight_splitk(const bdetr_conv_desc* d) {
