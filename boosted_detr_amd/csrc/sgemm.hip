@@ -302,8 +302,10 @@ __device__ __forceinline__ void direct_epilogue(f32x16 (&acc)[BM / WM / 32][BN /
 
 // NS = LDS stages: the loads of K-step t + NS - 1 are issued while K-step t computes and a counted s_waitcnt
 // vmcnt leaves the younger stages in flight across the (raw) barrier.
-template <int BM, int BN, int WM, int WN, int NS, class LA, class LB, bool XX, bool F16>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && 2 * lds_bytes_for(BM, BN, NS) <= 160 * 1024) ? 2 : (WM * WN == 8 ? 2 : 1))
+constexpr int default_occ(int bm, int bn, int wm, int wn, int ns) { return (wm * wn == 4 && 2 * lds_bytes_for(bm, bn, ns) <= 160 * 1024) ? 2 : (wm * wn == 8 ? 2 : 1); }
+
+template <int BM, int BN, int WM, int WN, int NS, class LA, class LB, bool XX, bool F16, int OCC = default_occ(BM, BN, WM, WN, NS)>
+__global__ __launch_bounds__(WM * WN * 64, OCC)
 void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
 {
     constexpr int NW = WM * WN, NT = NW * 64;
@@ -596,8 +598,11 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
 // equal on the MFMA-bound 3x3 layers, slower on the short-K 1x1 layers), next-stage loads interleaved between the MFMA
 // groups instead of issued up front (15.8 ms), 3- and 4-stage rings at two workgroups per CU on 128x64 / 64x64 tiles for
 // the short-K 1x1 layers (equal or slower on every layer: those layers were bound by the serial load -> MFMA -> store
-// phases of a workgroup's life, which the persistent loop overlaps, not by bytes in flight).  The template still takes
-// NS and WM x WN.
+// phases of a workgroup's life, which the persistent loop overlaps, not by bytes in flight); after the epilogue
+// rewrite, again a 3-stage ring with counted waits on 128x64 tiles at two workgroups per CU (13.4 ms for all layers vs
+// 12.4) and 128x64 two-stage tiles at three workgroups per CU (13.1 ms).  More bytes in flight or more resident
+// workgroups do not help: at 27 B/clk/CU the staging already runs near the L2 -> LDS fill rate the guide measured for
+// LDS-DMA gathers (66-73 GB/s per CU), which is what a bigger FLOP-per-staged-byte ratio would have to relieve.
 enum { T_128x128 = 0, T_128x64 = 1, T_64x64 = 2, T_COUNT = 3 };
 const int TILE_BM[T_COUNT] = {128, 128, 64};
 const int TILE_BN[T_COUNT] = {128, 64, 64};
@@ -627,7 +632,7 @@ int choose_tile(int64_t I, int64_t J, int64_t z) {
     return T_64x64;
 }
 
-template <int BM, int BN, int WM, int WN, int NS, class LA, class LB, bool XX, bool F16>
+template <int BM, int BN, int WM, int WN, int NS, class LA, class LB, bool XX, bool F16, int OCC = default_occ(BM, BN, WM, WN, NS)>
 int launch_cfg(const typename LA::Op& a, const typename LB::Op& b, GemmParams g, int zdim, hipStream_t st, int kind) {
     g.tiles_i = (int)cdiv64(g.I, BM);
     g.tiles_j = (int)cdiv64(g.J, BN);
@@ -645,14 +650,14 @@ int launch_cfg(const typename LA::Op& a, const typename LB::Op& b, GemmParams g,
         static int resident = 0;
         if (resident == 0) {
             int occ = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, sgemm_kernel<BM, BN, WM, WN, NS, LA, LB, XX, F16>, WM * WN * 64, 0) != hipSuccess || occ < 1) occ = 1;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, sgemm_kernel<BM, BN, WM, WN, NS, LA, LB, XX, F16, OCC>, WM * WN * 64, 0) != hipSuccess || occ < 1) occ = 1;
             resident = occ * num_cus() / 8 * 8;
             if (resident < 8) resident = 8;
         }
         BDETR_CHECK_ARG(zdim == 1 && g.splitk == 1, "sgemm: the persistent kernels take no split-K / batch dimension");
         if ((int)grid.x > resident) grid.x = resident;
     }
-    hipLaunchKernelGGL((sgemm_kernel<BM, BN, WM, WN, NS, LA, LB, XX, F16>), grid, dim3(WM * WN * 64), 0, st, a, b, g);
+    hipLaunchKernelGGL((sgemm_kernel<BM, BN, WM, WN, NS, LA, LB, XX, F16, OCC>), grid, dim3(WM * WN * 64), 0, st, a, b, g);
     if (prof) prof_end(st);
     return bdetr_launch_status("sgemm");
 }
