@@ -601,6 +601,26 @@ extern "C" int bdetr_bn_apply_p16(const float* x, const float* mean, const float
     return bdetr_launch_status("bn_apply_p16");
 }
 
+namespace {
+// x <- x * mask, mask = bn_apply_p16's 1-bit ReLU mask (the fallback for a lazily masked skip gradient, see ops.py)
+__global__ __launch_bounds__(256) void relu_mask_apply_kernel(float* __restrict__ x, const unsigned long long* __restrict__ mask, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned pm = relu_mask_bits4(mask, i);
+        f32x4 v = reinterpret_cast<f32x4*>(x)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (!((pm >> e) & 1u)) v[e] = 0.f;
+        reinterpret_cast<f32x4*>(x)[i] = v;
+    }
+}
+}  // namespace
+
+extern "C" int bdetr_relu_mask_apply(float* x, const uint64_t* relu_mask, int64_t n, void* stream) {
+    BDETR_CHECK_ARG(x && relu_mask && n > 0 && n % 4 == 0, "bdetr_relu_mask_apply: bad arguments (n %% 4 == 0 required)");
+    hipLaunchKernelGGL(relu_mask_apply_kernel, dim3(ew_grid(n / 4, 256, 2)), dim3(256), 0, (hipStream_t)stream, x,
+                       reinterpret_cast<const unsigned long long*>(relu_mask), n / 4);
+    return bdetr_launch_status("relu_mask_apply");
+}
+
 extern "C" int bdetr_bn_bwd_p16(const float* dout, const void* out, int out_p16, const float* x, const float* mean,
                                 const float* rstd, const float* gamma, const float* beta, int relu, int frozen,
                                 float* dx32, void* dx_bf16, float* dgamma, float* dbeta, float* dresidual,

@@ -244,21 +244,44 @@ __device__ __forceinline__ void direct_epilogue(f32x16 (&acc)[BM / WM / 32][BN /
 
     const __amdgpu_buffer_rsrc_t rsC = tile_rsrc(g.c);
     if (g.mode == ST_ACCUM) {
+        // acc_mask: the old value is a block-output gradient that still needs the unit's ReLU mask (1 bit per element:
+        // element n = row * ldc + col lives in 64-bit word (n >> 8) * 4 + (n & 3), bit (n >> 2) & 63).  The masked and the
+        // plain form are two complete copies (loads ... adds): with the mask loads under a run-time `if` in the middle of
+        // one copy, a few of the plain form's old values were consumed before they had landed (sporadic 64-byte runs of
+        // the C tile came out as product + 0).
+        auto accumulate = [&](auto masked_c) {
+            constexpr bool MASKED = decltype(masked_c)::value;
+            const __amdgpu_buffer_rsrc_t rsM = make_rsrc(g.acc_mask, MASKED ? (unsigned)(((int64_t)g.I * g.ldc + 255) >> 8) * 32u : 0u);   // exactly the mask: rows past I read as 0
 #pragma unroll
-        for (int a = 0; a < TM; ++a) {
-            float old[TN][16];
-            unsigned ro = (unsigned)(a * 32) * ldc4;
+            for (int a = 0; a < TM; ++a) {
+                float old[TN][16];
+                unsigned keep[TN][16];
+                unsigned ro = (unsigned)(a * 32) * ldc4;
+                unsigned nrow = (unsigned)(i0 + wm * WTM + 4 * lh + a * 32) * (unsigned)g.ldc + (unsigned)jl;      // element index of (e = 0, b = 0)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
+                for (int e = 0; e < 16; ++e) {
 #pragma unroll
-                for (int b = 0; b < TN; ++b) old[b][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsC, vcol[b] + ro, 0, 0));
-                ro += (e & 3) == 3 ? 5u * ldc4 : ldc4;
+                    for (int b = 0; b < TN; ++b) {
+                        old[b][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsC, vcol[b] + ro, 0, 0));
+                        if constexpr (MASKED) {
+                            const unsigned n = nrow + 32u * b;
+                            const unsigned wo = vcol[b] == FAR ? OOB : ((((n >> 8) << 2) | (n & 3u)) << 3) + ((n >> 5) & 4u);     // the dword holding bit (n >> 2) & 63
+                            keep[b][e] = (__builtin_amdgcn_raw_buffer_load_b32(rsM, wo, 0, 0) >> ((n >> 2) & 31u)) & 1u;
+                        }
+                    }
+                    ro += (e & 3) == 3 ? 5u * ldc4 : ldc4;
+                    nrow += ((e & 3) == 3 ? 5u : 1u) * (unsigned)g.ldc;
+                }
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        if constexpr (MASKED) acc[a][b][e] += keep[b][e] ? old[b][e] : 0.f;
+                        else acc[a][b][e] += old[b][e];
+                    }
             }
-#pragma unroll
-            for (int b = 0; b < TN; ++b)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[a][b][e] += old[b][e];
-        }
+        };
+        if (g.acc_mask != nullptr) accumulate(std::true_type{}); else accumulate(std::false_type{});
     }
     if (g.bnb_y != nullptr) {
         // fused BatchNorm-backward sums of g = C * [y' > 0] and g * xhat per column, straight from the accumulator
@@ -763,13 +786,14 @@ extern "C" int bdetr_p16_conv2d_bwd_data_stat_chunks(const bdetr_conv_desc* d) {
 // (bdetr_p16_pack_conv_weights); dx: fp32 [N,H,W,C].  bn (may be null): dx is the gradient of the BatchNorm(+ReLU) output
 // whose pre-normalisation tensor is bn->y - fuse that layer's backward reduction into this epilogue.
 static int p16_bwd_data(const void* dy_bf16, const void* wt_bf16, float* dx, const bdetr_conv_desc* d, int accumulate,
-                        const bdetr_bn_bwd_fuse* bn, void* stream) {
+                        const bdetr_bn_bwd_fuse* bn, const uint64_t* acc_mask, void* stream) {
     if (int e = check_conv(d, "bdetr_p16_conv2d_bwd_data")) return e;
     BDETR_CHECK_ARG(dy_bf16 && wt_bf16 && dx, "bdetr_p16_conv2d_bwd_data: null pointer");
     hipStream_t st = (hipStream_t)stream;
     const int M = d->N * d->OH * d->OW;
     GemmParams g; init_params(g);
     g.c = dx; g.ldc = d->C; g.mode = accumulate ? ST_ACCUM : ST_STORE;
+    g.acc_mask = reinterpret_cast<const unsigned long long*>(acc_mask);
     if (bn != nullptr) {
         BDETR_CHECK_ARG(!accumulate && d->stride == 1 && d->C % 4 == 0 && aligned16(dx) && aligned16(bn->y),
                         "bdetr_p16_conv2d_bwd_data_bnstats: needs a plain store of 16-byte aligned rows (no accumulate, stride 1)");
@@ -802,12 +826,19 @@ static int p16_bwd_data(const void* dy_bf16, const void* wt_bf16, float* dx, con
 
 extern "C" int bdetr_p16_conv2d_bwd_data(const void* dy_bf16, const void* wt_bf16, float* dx,
                                          const bdetr_conv_desc* d, int accumulate, void* stream) {
-    return p16_bwd_data(dy_bf16, wt_bf16, dx, d, accumulate, nullptr, stream);
+    return p16_bwd_data(dy_bf16, wt_bf16, dx, d, accumulate, nullptr, nullptr, stream);
+}
+extern "C" int bdetr_p16_conv2d_bwd_data_masked_accum(const void* dy_bf16, const void* wt_bf16, float* dx, const uint64_t* relu_mask,
+                                                      const bdetr_conv_desc* d, void* stream) {
+    BDETR_CHECK_ARG(relu_mask != nullptr && d != nullptr && d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0,
+                    "bdetr_p16_conv2d_bwd_data_masked_accum: 1x1 stride-1 convolutions only, mask required");
+    BDETR_CHECK_ARG((int64_t)d->N * d->H * d->W * d->C < (1LL << 32), "bdetr_p16_conv2d_bwd_data_masked_accum: more than 2^32 elements");
+    return p16_bwd_data(dy_bf16, wt_bf16, dx, d, 1, nullptr, relu_mask, stream);
 }
 extern "C" int bdetr_p16_conv2d_bwd_data_bnstats(const void* dy_bf16, const void* wt_bf16, float* dx,
                                                  const bdetr_conv_desc* d, const bdetr_bn_bwd_fuse* bn, void* stream) {
     BDETR_CHECK_ARG(bn != nullptr, "bdetr_p16_conv2d_bwd_data_bnstats: null bn descriptor");
-    return p16_bwd_data(dy_bf16, wt_bf16, dx, d, 0, bn, stream);
+    return p16_bwd_data(dy_bf16, wt_bf16, dx, d, 0, bn, nullptr, stream);
 }
 
 static int wgrad_tile(const bdetr_conv_desc* d) {

@@ -159,6 +159,17 @@ def initializer(kind: str) -> Callable:
 # ----------------------------------------------------------------------------------------
 # tape
 # ----------------------------------------------------------------------------------------
+def materialise(g):
+    """A gradient tensor tagged ``_lazy_mask`` stands for tensor * mask (the skip gradient of a residual unit, handed on
+    without applying the unit's ReLU bit mask: ops.conv_bn).  Ops that know the tag fold the mask into their own kernel;
+    for everybody else the mask is applied in place here."""
+    m = getattr(g, "_lazy_mask", None)
+    if m is not None:
+        K.relu_mask_apply_(g, m)
+        del g._lazy_mask
+    return g
+
+
 class Tape:
     """Records (outputs, inputs, backward_fn) triples; ``backward`` replays them in reverse and
     sums gradients that reach the same tensor (residual branches, shared keys/values)."""
@@ -175,6 +186,8 @@ class Tape:
             gouts = [grads.pop(id(o), None) for o in outputs]
             if all(g is None for g in gouts):
                 continue
+            if not getattr(fn, "accepts_lazy", False):
+                gouts = [materialise(g) for g in gouts]
             acc = None
             if getattr(fn, "wants_acc", False):
                 # offer the op the gradient tensors already accumulated for its inputs (only when the
@@ -197,6 +210,7 @@ class Tape:
                     have = grads[key]
                     if acc is not None and acc[i] is not None and g is acc[i]:
                         continue                                    # the op already accumulated into the offered tensor
+                    g, have = materialise(g), materialise(have)
                     if getattr(have, "_bdetr_owned", False):       # sole owner: accumulate in place
                         K.axpy_(1.0, g.view(have.shape), have)
                     else:

@@ -350,6 +350,25 @@ def p16_conv2d_bwd_data(dy_bf16, wt_bf16, g: ConvGeom, dx: Optional[torch.Tensor
     return dx
 
 
+def relu_mask_apply_(x: torch.Tensor, relu_mask: torch.Tensor) -> torch.Tensor:
+    """x <- x * relu_mask (bn_apply_p16's bit mask) in place."""
+    _chk(x)
+    _chk(relu_mask, dtype=torch.int64)
+    check(_lib.lib().bdetr_relu_mask_apply(_p(x), _p(relu_mask), x.numel(), _stream()), "relu_mask_apply")
+    return x
+
+
+def p16_conv2d_bwd_data_masked_accum(dy_bf16, wt_bf16, g: ConvGeom, dx: torch.Tensor, relu_mask: torch.Tensor):
+    """dx (the gradient of a residual unit's output on entry) <- conv_transpose(dy) + dx * relu_mask, in place: the unit's skip
+    branch merged inside the 1x1 backward-data epilogue of its first convolution."""
+    _chk(dy_bf16, wt_bf16, dx)
+    _chk(relu_mask, dtype=torch.int64)
+    d = g.desc()
+    check(_lib.lib().bdetr_p16_conv2d_bwd_data_masked_accum(_p(dy_bf16), _p(wt_bf16), _p(dx), _p(relu_mask), C.byref(d), _stream()),
+          "p16_conv2d_bwd_data_masked_accum")
+    return dx
+
+
 def p16_conv2d_bwd_data_bnstats(dy_bf16, wt_bf16, g: ConvGeom, y_prev, mean, rstd, gamma, beta, relu: bool):
     """Backward-data whose output is the gradient of the BatchNorm(+ReLU) output that fed this conv (pre-normalisation tensor
     y_prev, no residual): returns (dx, (part_g, part_gx, nparts)) - that layer's backward reduction, done in this epilogue."""

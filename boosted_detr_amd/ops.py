@@ -16,7 +16,7 @@ from typing import Optional
 import torch
 
 from . import kernels as K
-from .engine import WEIGHTS_VERSION, Variable, current_tape, on_side_stream
+from .engine import WEIGHTS_VERSION, Variable, current_tape, materialise, on_side_stream
 
 # Dropout masks are keyed by (per-step seed, dropout site, element index).  The per-step seed lives in HBM
 # (one int64 the host rewrites before every step), the site salt is a launch argument: a captured step graph then
@@ -158,6 +158,7 @@ def _bn_backward(g2d, out2d, x2d, mean, rstd, bn: BNState, relu: bool, frozen: b
 #   t._p16f / t._p16b   P16-f16 / P16-bf16 copies (fp32-shaped torch tensors, never read as floats)
 #   t._p16_only         the handle IS the f16 copy: no fp32 tensor was materialised (links inside a bottleneck)
 P16_ENABLED = [os.environ.get("BDETR_P16", "1") != "0"]
+LAZY_SKIP = os.environ.get("BDETR_LAZY_SKIP", "1") != "0"      # residual units hand their skip gradient on unmasked (conv_bn.backward)
 
 
 def _p16_active() -> bool:
@@ -265,6 +266,9 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
         out = out2d.view(N, g.OH, g.OW, Kout)
 
     def backward(g_out, acc=None):
+        lazy_bits = getattr(g_out, "_lazy_mask", None)      # g_out still needs its producer's ReLU mask (see below)
+        if lazy_bits is not None and not (p16 and _p16_active() and not relu and residual is None):
+            g_out, lazy_bits = materialise(g_out), None
         g2d = _2d(g_out.contiguous())
         want_res = residual is not None
         if p16 and _p16_active():
@@ -277,8 +281,21 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
             if relu and want_res:
                 mask_src, mode = (out2d, 0) if out2d is not None else ((relu_bits, 2) if relu_bits is not None else (ob, 1))
             pre = getattr(g_out, "_bnb_parts", None)        # the reduction came with the gradient (fused into the consumer's epilogue)
-            dyb, _, _, _, dres = K.bn_bwd_p16(g2d, mask_src, y2d, mean, rstd, bn.gamma.value, relu, False, want_residual_grad=want_res,
+            # The skip gradient of a residual unit is g_out * mask.  With the bit mask at hand it is not written out: the
+            # incoming gradient tensor itself is handed to the shortcut's producer tagged with the mask, and the consumers
+            # that know the tag (the 1x1 backward-data below, the projection shortcut's BatchNorm backward) fold the mask into
+            # their own kernels - one 4-byte-per-element write per unit less (engine.materialise is the fallback).
+            lazy_skip = (want_res and mode == 2 and LAZY_SKIP and getattr(g_out, "_bdetr_owned", False) and lazy_bits is None
+                         and g_out.is_contiguous())
+            bn_relu = relu
+            if lazy_bits is not None:                       # this BatchNorm has no ReLU of its own: apply the incoming mask instead
+                mask_src, mode, bn_relu = lazy_bits, 2, True
+            dyb, _, _, _, dres = K.bn_bwd_p16(g2d, mask_src, y2d, mean, rstd, bn.gamma.value, bn_relu, False,
+                                              want_residual_grad=want_res and not lazy_skip,
                                               dgamma=sg.buf, dbeta=sb.buf, beta=bn.beta.value, out_p16=mode, pre=pre)
+            if lazy_skip:
+                dres = _own(g_out.view(residual.shape))
+                dres._lazy_mask = relu_bits
             sg.commit()
             sb.commit()
             dyb4 = dyb.view(N, g.OH, g.OW, Kout)
@@ -298,7 +315,12 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
                 _, wt = packed_weights(w, need_bwd=True)
                 ctx = getattr(x_handle, "_bn_ctx", None)
                 if acc is not None and acc[0] is not None:
-                    K.p16_conv2d_bwd_data(dyb4, wt, g, dx=acc[0].view(N, H, W, Cin), accumulate=True)
+                    skip_bits = getattr(acc[0], "_lazy_mask", None)
+                    if skip_bits is not None and R == 1 and S == 1 and stride == 1 and pad == 0:
+                        K.p16_conv2d_bwd_data_masked_accum(dyb4, wt, g, acc[0].view(N, H, W, Cin), skip_bits)
+                        del acc[0]._lazy_mask
+                    else:
+                        K.p16_conv2d_bwd_data(dyb4, wt, g, dx=materialise(acc[0]).view(N, H, W, Cin), accumulate=True)
                     dx = acc[0]
                 elif ctx is not None and stride == 1:
                     dx, parts = K.p16_conv2d_bwd_data_bnstats(dyb4, wt, g, *ctx)
@@ -306,7 +328,7 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
                     dx._bnb_parts = parts
                 else:
                     dx = _own(K.p16_conv2d_bwd_data(dyb4, wt, g))
-            return dx, (_own(dres.view(residual.shape)) if want_res else None)
+            return dx, ((dres if lazy_skip else _own(dres.view(residual.shape))) if want_res else None)
         x32 = as_fp32(x)
         out32 = out2d if (out2d is not None or not (relu and want_res)) else _2d(as_fp32(out))
         dy, dres = _bn_backward(g2d, out32, y2d, mean, rstd, bn, relu, not use_batch, want_res)
@@ -331,7 +353,7 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
         if x_needs_grad:
             if acc is not None and acc[0] is not None:
                 # residual merge fused into the GEMM epilogue: dx += conv_transpose(dy) (no separate add pass)
-                dx = K.conv2d_bwd_data(dy4, w.value, g, dx=acc[0].view(N, H, W, Cin), accumulate=True)
+                dx = K.conv2d_bwd_data(dy4, w.value, g, dx=materialise(acc[0]).view(N, H, W, Cin), accumulate=True)
                 dx = acc[0]
             else:
                 dx = _own(K.conv2d_bwd_data(dy4, w.value, g))
@@ -339,6 +361,7 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
         return dx, dr
 
     backward.wants_acc = True
+    backward.accepts_lazy = True
     _rec([out], [x_handle, res_handle], backward)
     return out
 

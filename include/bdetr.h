@@ -189,6 +189,15 @@ typedef struct {
     float* part_g; float* part_gx;
 } bdetr_bn_bwd_fuse;
 int bdetr_p16_conv2d_bwd_data_stat_chunks(const bdetr_conv_desc* d);
+/* 1x1 stride-1 backward-data that merges the skip branch of a residual unit: on entry dx holds the gradient of the unit's
+ * OUTPUT (after the ReLU), on exit dx = conv_transpose(dy) + dx * relu_mask, relu_mask = the 1-bit-per-element mask
+ * bdetr_bn_apply_p16 wrote for that unit.  The masked gradient of the skip branch (Keras: the Add + Activation of
+ * keras.applications.resnet block1, reference backbone.py:37-38) is never materialised. */
+/* x <- x * relu_mask in place (n elements, n % 4 == 0): materialises a gradient that was handed on with its unit's ReLU mask
+ * still to be applied, for consumers other than bdetr_p16_conv2d_bwd_data_masked_accum / bdetr_bn_bwd_p16(out_p16 = 2). */
+int bdetr_relu_mask_apply(float* x, const uint64_t* relu_mask, int64_t n, void* stream);
+int bdetr_p16_conv2d_bwd_data_masked_accum(const void* dy_bf16, const void* wt_bf16, float* dx, const uint64_t* relu_mask,
+                                           const bdetr_conv_desc* d, void* stream);
 int bdetr_p16_conv2d_bwd_data_bnstats(const void* dy_bf16, const void* wt_bf16, float* dx,
                                       const bdetr_conv_desc* d, const bdetr_bn_bwd_fuse* bn, void* stream);
 /* dw fp32 [K][R][S][C] += sum over pixels of dy x patches(x); with splitk > 1 the slices add with float

@@ -206,3 +206,31 @@ def test_bn_backward_reduction_fused_into_the_bwd_data_epilogue(cuda, N, H, W, C
     got = k.bn_bwd_p16(dx.view(rows, C), None, y_prev, mean, rstd, gamma, relu, False, beta=beta, want_fp32=True, pre=parts)
     close(got[2], ref[2], rtol=1e-5); close(got[3], ref[3], rtol=1e-5)          # dgamma, dbeta
     close(got[1], ref[1], rtol=1e-5)                                             # dx of the BatchNorm
+
+
+@pytest.mark.parametrize("N,H,W,C,K", [(2, 20, 20, 64, 256), (3, 9, 11, 256, 64), (1, 5, 6, 40, 72), (16, 40, 40, 1024, 256), (4, 160, 160, 256, 64)])
+def test_masked_skip_accumulate_in_the_bwd_data_epilogue(cuda, N, H, W, C, K):
+    """bdetr_p16_conv2d_bwd_data_masked_accum: dx <- conv_transpose(dy) + dx * relu_mask with bn_apply_p16's bit mask (the skip
+    branch of a residual unit merged in the first convolution's backward-data epilogue), and bdetr_relu_mask_apply, its
+    stand-alone fallback (bit-exact)."""
+    from boosted_detr_amd import kernels as k
+    g = k.ConvGeom(N, H, W, C, K, 1, 1, 1, 0)
+    rows = N * H * W
+    # the unit's output: relu(bn(y) + shortcut); only its sign pattern matters here
+    y = dev(rnd(rows, C, seed=1) * 2 + 0.3)
+    gamma, beta = dev(1 + 0.1 * rnd(C, seed=2)), dev(0.1 * rnd(C, seed=3))
+    mean, rstd = k.bn_stats(rows, C, k.colstats(y), 1.001e-5, 0.99, True, dev(torch.zeros(C)), dev(torch.ones(C)), like=y)
+    shortcut = dev(rnd(rows, C, seed=4))
+    out32, _, _, bits = k.bn_apply_p16(y, mean, rstd, gamma, beta, shortcut, True, want_fp32=True, want_f16=False, want_bf16=False, want_mask=True)
+    on = (out32 > 0).double().cpu()
+    d_out = rnd(N, H, W, C, seed=5)
+    w = rnd(K, 1, 1, C, seed=6, scale=C ** -0.5)
+    dy = rnd(N, H, W, K, seed=7)
+    _, wt = k.p16_pack_conv_weights(dev(w), want_fwd=False)
+    _, dyb = k.p16_pack(dev(dy), want_f16=False)
+    dx = dev(d_out)
+    k.p16_conv2d_bwd_data_masked_accum(dyb, wt, g, dx, bits)
+    want = dy.double().reshape(rows, K) @ w.double().reshape(K, C) + d_out.double().reshape(rows, C) * on
+    close(dx.view(rows, C), want, rtol=6e-5)
+    masked = k.relu_mask_apply_(dev(d_out).view(rows, C), bits)
+    assert torch.equal(masked.cpu().double(), d_out.double().reshape(rows, C) * on)
