@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define BDETR_ABI_VERSION 3
+#define BDETR_ABI_VERSION 4
 
 int         bdetr_abi_version(void);
 const char* bdetr_last_error(void);
