@@ -623,7 +623,8 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
 // the short-K 1x1 layers (equal or slower on every layer: those layers were bound by the serial load -> MFMA -> store
 // phases of a workgroup's life, which the persistent loop overlaps, not by bytes in flight); after the epilogue
 // rewrite, again a 3-stage ring with counted waits on 128x64 tiles at two workgroups per CU (13.4 ms for all layers vs
-// 12.4) and 128x64 two-stage tiles at three workgroups per CU (13.1 ms).  More bytes in flight or more resident
+// 12.4), 128x64 two-stage tiles at three workgroups per CU (13.1 ms) and 8-wave 256x128 tiles for the patch kernels
+// (13.1 ms: equal on the 40x40 3x3 layers, slower on the others).  More bytes in flight or more resident
 // workgroups do not help: at 27 B/clk/CU the staging already runs near the L2 -> LDS fill rate the guide measured for
 // LDS-DMA gathers (66-73 GB/s per CU), which is what a bigger FLOP-per-staged-byte ratio would have to relieve.
 enum { T_128x128 = 0, T_128x64 = 1, T_64x64 = 2, T_COUNT = 3 };
