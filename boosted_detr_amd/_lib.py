@@ -33,6 +33,10 @@ class GemmDesc(C.Structure):
     ]
 
 
+class BnAffine(C.Structure):
+    _fields_ = [("mean", C.c_void_p), ("rstd", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p)]
+
+
 class BnBwdFuse(C.Structure):
     _fields_ = [("y", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("relu", C.c_int),
                 ("part_g", C.c_void_p), ("part_gx", C.c_void_p)]
@@ -72,7 +76,7 @@ SIGNATURES = {
     "bdetr_conv2d_bwd_data": (I, [P, P, P, C.POINTER(ConvDesc), I, P]),
     "bdetr_conv2d_bwd_weight": (I, [P, P, P, C.POINTER(ConvDesc), I, P]),
     "bdetr_conv2d_bwd_weight_splitk": (I, [C.POINTER(ConvDesc)]),
-    "bdetr_bn_apply_p16": (I, [P, P, P, P, P, P, I, I, P, P, P, P, P, L, I, P]),
+    "bdetr_bn_apply_p16": (I, [P, P, P, P, P, P, I, C.POINTER(BnAffine), I, P, P, P, P, P, L, I, P]),
     "bdetr_bn_bwd_p16": (I, [P, P, I, P, P, P, P, P, I, I, P, P, P, P, P, P, P, P, I, L, I, P]),
     "bdetr_p16_supported": (I, [C.POINTER(ConvDesc)]),
     "bdetr_p16_pack": (I, [P, L, P, P, P, P]),

@@ -37,12 +37,12 @@ class _ConvBN(Layer):
         self.bn = ops.BNState(gamma, beta, mm, mv, RESNET_BN_EPS)
         self.built = True
 
-    def call(self, inputs, training=False, relu=True, residual=None, x_needs_grad=True, want_fp32=True, want_p16=False):
+    def call(self, inputs, training=False, relu=True, residual=None, x_needs_grad=True, want_fp32=True, want_p16=False, defer_apply=False):
         x = inputs[0]
         # S18: BN uses batch statistics only when training AND the layer is trainable
         return ops.conv_bn(x, self.kernel, self.bias, self.bn, self.stride, self.pad, relu, residual=residual,
                            training=training, bn_batch_stats=training and self.trainable, x_needs_grad=x_needs_grad,
-                           want_fp32=want_fp32, want_p16=want_p16)
+                           want_fp32=want_fp32, want_p16=want_p16, defer_apply=defer_apply)
 
 
 class ResNet(Layer):
@@ -83,7 +83,8 @@ class ResNet(Layer):
         # hi halves of the bf16 pair); only the last one, which leaves the backbone, is written in fp32.
         for i, blk in enumerate(self.blocks):
             last = i + 1 == len(self.blocks)
-            sc = blk["short"]([x], training=training, relu=False) if blk["short"] is not None else x
+            # projection shortcut: its BatchNorm is applied inside c3's pass (ops.conv_bn defer_apply)
+            sc = blk["short"]([x], training=training, relu=False, defer_apply=True) if blk["short"] is not None else x
             y = blk["c1"]([x], training=training, relu=True, want_fp32=False, want_p16=True)
             y = blk["c2"]([y], training=training, relu=True, want_fp32=False, want_p16=True)
             x = blk["c3"]([y], training=training, relu=True, residual=sc, want_fp32=last, want_p16=not last)     # BN -> Add([shortcut, x]) -> ReLU

@@ -57,7 +57,17 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     const int cx = threadIdx.x & 31, py = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cx;
     double a = 0, b = 0;
-    if (c < C) for (int p = py; p < nparts; p += 8) { a += psum[(int64_t)p * C + c]; b += psq[(int64_t)p * C + c]; }
+    if (c < C) {
+        int p = py;
+        for (; p + 3 * 8 < nparts; p += 4 * 8) {                      // 4 rows' loads in flight per thread, fixed order
+            float va[4], vb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { va[u] = psum[(int64_t)(p + 8 * u) * C + c]; vb[u] = psq[(int64_t)(p + 8 * u) * C + c]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a += va[u]; b += vb[u]; }
+        }
+        for (; p < nparts; p += 8) { a += psum[(int64_t)p * C + c]; b += psq[(int64_t)p * C + c]; }
+    }
     s1[threadIdx.x] = a; s2[threadIdx.x] = b;
     __syncthreads();
     if (py == 0 && c < C) {
@@ -89,7 +99,17 @@ __global__ __launch_bounds__(256) void fold_partials2_kernel(const float* __rest
     const int cx = threadIdx.x & 31, py = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cx, o = blockIdx.y;
     float a = 0.f, b = 0.f;
-    if (c < C) for (int p = o + py * nout; p < nparts; p += 8 * nout) { a += pa[(int64_t)p * C + c]; b += pb[(int64_t)p * C + c]; }
+    if (c < C) {
+        int p = o + py * nout;
+        for (; p + 3 * 8 * nout < nparts; p += 4 * 8 * nout) {        // 4 rows' loads in flight per thread, fixed order
+            float va[4], vb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { va[u] = pa[(int64_t)(p + 8 * nout * u) * C + c]; vb[u] = pb[(int64_t)(p + 8 * nout * u) * C + c]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a += va[u]; b += vb[u]; }
+        }
+        for (; p < nparts; p += 8 * nout) { a += pa[(int64_t)p * C + c]; b += pb[(int64_t)p * C + c]; }
+    }
     s1[threadIdx.x] = a; s2[threadIdx.x] = b;
     __syncthreads();
     if (py == 0 && c < C) {
@@ -112,7 +132,19 @@ __global__ __launch_bounds__(256) void sum_partials2_kernel(const float* __restr
     const int cx = threadIdx.x & 7, py = threadIdx.x >> 3;
     const int c = blockIdx.x * 8 + cx;
     double a = 0, b = 0;
-    if (c < C) for (int p = py; p < nparts; p += 32) { a += pa[(int64_t)p * C + c]; b += pb[(int64_t)p * C + c]; }
+    if (c < C) {
+        // 8 rows' loads in flight per thread (the rolled loop waited for each pair of loads before issuing the next:
+        // 200 round trips on the 6,400 partial rows of a stage-2 layer); the summation order stays fixed
+        int p = py;
+        for (; p + 7 * 32 < nparts; p += 8 * 32) {
+            float va[8], vb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { va[u] = pa[(int64_t)(p + 32 * u) * C + c]; vb[u] = pb[(int64_t)(p + 32 * u) * C + c]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a += va[u]; b += vb[u]; }
+        }
+        for (; p < nparts; p += 32) { a += pa[(int64_t)p * C + c]; b += pb[(int64_t)p * C + c]; }
+    }
     s1[threadIdx.x] = a; s2[threadIdx.x] = b;
     __syncthreads();
     for (int s = 16; s > 0; s >>= 1) {          // fixed-order tree over the 32 phases
@@ -234,7 +266,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 // the backward pass agrees with what the forward wrote.
 __global__ __launch_bounds__(256) void bn_apply_p16_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           const void* __restrict__ residual, int residual_p16, int relu, float* __restrict__ out32,
+                                                           const void* __restrict__ residual, int residual_p16, bdetr_bn_affine rbn, int relu, float* __restrict__ out32,
                                                            void* __restrict__ out_f16, void* __restrict__ out_bf16, unsigned long long* __restrict__ relu_mask,
                                                            int* __restrict__ overflow_flag, int64_t n4, int c4n) {
     // n4 is even and the stride is even: the two lanes of a pair (one 8-element group) always run together
@@ -247,7 +279,14 @@ __global__ __launch_bounds__(256) void bn_apply_p16_kernel(const float* __restri
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = bn_affine(v[e], m[e], rs[e], g[e], b[e]);
         if (residual != nullptr) {
-            if (residual_p16) {
+            if (residual_p16 == 2) {
+                // the projection shortcut's BatchNorm, applied here: same bn_affine, same fp32 add as the two-pass form
+                const f32x4 rv = reinterpret_cast<const f32x4*>(residual)[i];
+                const f32x4 m2 = *reinterpret_cast<const f32x4*>(rbn.mean + c), rs2 = *reinterpret_cast<const f32x4*>(rbn.rstd + c);
+                const f32x4 g2 = *reinterpret_cast<const f32x4*>(rbn.gamma + c), b2 = *reinterpret_cast<const f32x4*>(rbn.beta + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] += bn_affine(rv[e], m2[e], rs2[e], g2[e], b2[e]);
+            } else if (residual_p16) {
                 float r4[4];
                 p16_load4_f16(residual, i, r4);
 #pragma unroll
@@ -591,12 +630,16 @@ extern "C" int bdetr_bn_bwd(const float* dout, const float* out, const float* x,
 }
 
 extern "C" int bdetr_bn_apply_p16(const float* x, const float* mean, const float* rstd, const float* gamma,
-                                  const float* beta, const void* residual, int residual_p16, int relu, float* out32, void* out_f16, void* out_bf16,
+                                  const float* beta, const void* residual, int residual_p16, const bdetr_bn_affine* residual_bn, int relu,
+                                  float* out32, void* out_f16, void* out_bf16,
                                   uint64_t* relu_mask, int* overflow_flag, int64_t rows, int C, void* stream) {
     BDETR_CHECK_ARG(x && mean && rstd && gamma && beta && (out32 || out_f16 || out_bf16) && rows > 0 && C > 0 && C % 8 == 0,
                     "bdetr_bn_apply_p16: bad arguments (C %% 8 == 0 required)");
+    BDETR_CHECK_ARG(residual_p16 != 2 || (residual && residual_bn && residual_bn->mean && residual_bn->rstd && residual_bn->gamma && residual_bn->beta),
+                    "bdetr_bn_apply_p16: residual_p16 = 2 needs the raw shortcut tensor and its BatchNorm");
+    const bdetr_bn_affine rbn = residual_p16 == 2 ? *residual_bn : bdetr_bn_affine{nullptr, nullptr, nullptr, nullptr};
     const int64_t n4 = rows * C / 4;
-    hipLaunchKernelGGL(bn_apply_p16_kernel, dim3(ew_grid(n4, 256, 2)), dim3(256), 0, (hipStream_t)stream, x, mean, rstd, gamma, beta, residual, residual_p16, relu,
+    hipLaunchKernelGGL(bn_apply_p16_kernel, dim3(ew_grid(n4, 256, 2)), dim3(256), 0, (hipStream_t)stream, x, mean, rstd, gamma, beta, residual, residual_p16, rbn, relu,
                        out32, out_f16, out_bf16, reinterpret_cast<unsigned long long*>(relu_mask), overflow_flag, n4, C / 4);
     return bdetr_launch_status("bn_apply_p16");
 }

@@ -13,7 +13,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import BnBwdFuse, ConvDesc, GemmDesc, LossDesc, check
+from ._lib import BnAffine, BnBwdFuse, ConvDesc, GemmDesc, LossDesc, check
 
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 
@@ -279,17 +279,24 @@ def p16_pack_conv_weights(w, want_fwd=True, want_bwd=True):
 
 
 def bn_apply_p16(x2d, mean, rstd, gamma, beta, residual=None, relu=False, want_fp32=True, want_f16=True, want_bf16=True,
-                 residual_p16=False, want_mask=False):
+                 residual_p16=False, want_mask=False, residual_bn=None):
     """bn_apply with P16 outputs: returns (out32 | None, out_f16 | None, out_bf16 | None[, relu bit mask]).  residual_p16:
-    `residual` is the f16 pair copy of the shortcut tensor.  want_mask: also return the 1-bit-per-element ReLU mask
+    `residual` is the f16 pair copy of the shortcut tensor.  residual_bn = (mean, rstd, gamma, beta): `residual` is the RAW
+    output of the projection shortcut's convolution, normalised here.  want_mask: also return the 1-bit-per-element ReLU mask
     (int64 words) the backward pass of a residual unit reads instead of the forward output."""
     _chk(x2d, mean, rstd, gamma, beta, residual)
+    rbn = None
+    if residual_bn is not None:
+        _chk(*residual_bn)
+        assert residual is not None and not residual_p16
+        rbn = C.byref(BnAffine(*(_p(t) for t in residual_bn)))
+        residual_p16 = 2
     rows, Cc = x2d.shape
     o32 = torch.empty_like(x2d) if want_fp32 else None
     of = torch.empty_like(x2d) if want_f16 else None
     ob = torch.empty_like(x2d) if want_bf16 else None
     mask = torch.empty(((rows * Cc // 4 + 63) // 64) * 4, dtype=torch.int64, device=x2d.device) if want_mask else None
-    check(_lib.lib().bdetr_bn_apply_p16(_p(x2d), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(residual), int(residual_p16), int(relu), _p(o32),
+    check(_lib.lib().bdetr_bn_apply_p16(_p(x2d), _p(mean), _p(rstd), _p(gamma), _p(beta), _p(residual), int(residual_p16), rbn, int(relu), _p(o32),
                                         _p(of), _p(ob), _p(mask), _p(overflow_flag()) if want_f16 else None, rows, Cc, _stream()), "bn_apply_p16")
     return (o32, of, ob, mask) if want_mask else (o32, of, ob)
 

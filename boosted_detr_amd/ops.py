@@ -166,9 +166,13 @@ def _p16_active() -> bool:
 
 
 def as_fp32(t: torch.Tensor) -> torch.Tensor:
-    """The fp32 tensor behind a handle (unpacks a P16-only handle: 2^-23 relative round trip)."""
+    """The fp32 tensor behind a handle (unpacks a P16-only handle: 2^-23 relative round trip; applies a deferred
+    BatchNorm: conv_bn(defer_apply=True))."""
     if getattr(t, "_p16_only", False):
         return K.p16_unpack(t._p16f, True).view(t.shape)
+    dbn = getattr(t, "_deferred_bn", None)
+    if dbn is not None:
+        return K.bn_apply(_2d(t), *dbn, None, False).view(t.shape)
     return t
 
 
@@ -221,8 +225,12 @@ def packed_weights(w: Variable, need_bwd: bool = True):
 
 def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int, pad: int, relu: bool,
             residual: Optional[torch.Tensor] = None, training: bool = False, bn_batch_stats: Optional[bool] = None,
-            x_needs_grad: bool = True, want_fp32: bool = True, want_p16: bool = False) -> torch.Tensor:
+            x_needs_grad: bool = True, want_fp32: bool = True, want_p16: bool = False, defer_apply: bool = False) -> torch.Tensor:
     """Conv2D(+bias) -> BatchNormalization -> [+ residual] -> [ReLU]  (keras ResNet-50 block unit).
+
+    defer_apply (projection shortcut, no ReLU, no residual; P16 path only): the statistics are reduced but the normalised
+    tensor is not written - the returned handle is the RAW convolution output tagged `_deferred_bn`, and the unit that takes
+    it as `residual` applies both BatchNorms in its one pass (bn_apply_p16 residual_bn; as_fp32 is the fallback).
 
     want_p16: the consumer is another conv_bn - also emit the packed copies of the output (P16 path only);
     want_fp32=False: no fp32 output at all, the returned handle is the f16 copy (valid on the P16 path only,
@@ -234,7 +242,8 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
     p16 = training and use_batch and _p16_active() and K.p16_supported(g)
     x_handle, res_handle = x, residual                 # the Tape keys gradients by the handles their producers returned
     res_p16 = p16 and residual is not None and getattr(residual, "_p16_only", False)
-    if residual is not None and not res_p16:
+    res_bn = getattr(residual, "_deferred_bn", None) if (p16 and residual is not None) else None
+    if residual is not None and not res_p16 and res_bn is None:
         residual = as_fp32(residual)
     res2d = _2d(residual) if residual is not None else None     # a P16-only handle IS its f16 pair copy
     xb = ob = relu_bits = None
@@ -247,11 +256,17 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
         fp32_out = want_fp32 or not want_p16
         # a residual unit without an fp32 output: its backward ReLU mask is a 1-bit-per-element by-product of this pass
         want_mask = relu and residual is not None and not fp32_out
-        o32, of, ob, *rest = K.bn_apply_p16(y2d, mean, rstd, bn.gamma.value, bn.beta.value, res2d, relu, want_fp32=fp32_out,
-                                            want_f16=want_p16, want_bf16=want_p16, residual_p16=res_p16, want_mask=want_mask)
-        relu_bits = rest[0] if want_mask else None
-        out2d = o32
-        out = (o32 if fp32_out else of).view(N, g.OH, g.OW, Kout)
+        if defer_apply and not relu and residual is None:
+            out2d = None
+            out = y.view(N, g.OH, g.OW, Kout)            # (a fresh handle: y itself stays this unit's own tensor)
+            out._deferred_bn = (mean, rstd, bn.gamma.value, bn.beta.value)
+        else:
+            o32, of, ob, *rest = K.bn_apply_p16(y2d, mean, rstd, bn.gamma.value, bn.beta.value, res2d, relu, want_fp32=fp32_out,
+                                                want_f16=want_p16, want_bf16=want_p16, residual_p16=res_p16, want_mask=want_mask,
+                                                residual_bn=res_bn)
+            relu_bits = rest[0] if want_mask else None
+            out2d = o32
+            out = (o32 if fp32_out else of).view(N, g.OH, g.OW, Kout)
         if want_p16:
             out._p16f, out._p16b, out._p16_only = of.view(out.shape), ob.view(out.shape), not fp32_out
         if not fp32_out and residual is None and os.environ.get("BDETR_BN_FUSE", "1") != "0":

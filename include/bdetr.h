@@ -151,8 +151,12 @@ int bdetr_conv2d_bwd_weight_splitk(const bdetr_conv_desc* d);
  * forward output, 1 its bf16 pair copy (the hi half has fp32's range: hi > 0 <=> value > 0), 2 the bit mask that
  * bdetr_bn_apply_p16 writes to relu_mask (uint64 words, (rows*C/4 + 63)/64*4 of them: one bit per element instead of
  * re-reading a 4-byte-per-element tensor in both backward passes). */
+/* residual_p16 = 2: `residual` is the RAW output of the projection shortcut's convolution and residual_bn its BatchNorm
+ * (batch statistics already reduced): out = relu?(bn(x) + residual_bn(residual)) in one pass - the shortcut's normalised
+ * tensor (Keras conv*_block1_0_bn) is never written or read back. */
+typedef struct { const float* mean; const float* rstd; const float* gamma; const float* beta; } bdetr_bn_affine;
 int bdetr_bn_apply_p16(const float* x, const float* mean, const float* rstd, const float* gamma,
-                       const float* beta, const void* residual, int residual_p16, int relu, float* out32,
+                       const float* beta, const void* residual, int residual_p16, const bdetr_bn_affine* residual_bn, int relu, float* out32,
                        void* out_f16, void* out_bf16, uint64_t* relu_mask, int* overflow_flag, int64_t rows, int C,
                        void* stream);
 int bdetr_bn_bwd_p16(const float* dout, const void* out, int out_p16, const float* x, const float* mean,
@@ -189,13 +193,13 @@ typedef struct {
     float* part_g; float* part_gx;
 } bdetr_bn_bwd_fuse;
 int bdetr_p16_conv2d_bwd_data_stat_chunks(const bdetr_conv_desc* d);
+/* x <- x * relu_mask in place (n elements, n % 4 == 0): materialises a gradient that was handed on with its unit's ReLU mask
+ * still to be applied, for consumers other than bdetr_p16_conv2d_bwd_data_masked_accum / bdetr_bn_bwd_p16(out_p16 = 2). */
+int bdetr_relu_mask_apply(float* x, const uint64_t* relu_mask, int64_t n, void* stream);
 /* 1x1 stride-1 backward-data that merges the skip branch of a residual unit: on entry dx holds the gradient of the unit's
  * OUTPUT (after the ReLU), on exit dx = conv_transpose(dy) + dx * relu_mask, relu_mask = the 1-bit-per-element mask
  * bdetr_bn_apply_p16 wrote for that unit.  The masked gradient of the skip branch (Keras: the Add + Activation of
  * keras.applications.resnet block1, reference backbone.py:37-38) is never materialised. */
-/* x <- x * relu_mask in place (n elements, n % 4 == 0): materialises a gradient that was handed on with its unit's ReLU mask
- * still to be applied, for consumers other than bdetr_p16_conv2d_bwd_data_masked_accum / bdetr_bn_bwd_p16(out_p16 = 2). */
-int bdetr_relu_mask_apply(float* x, const uint64_t* relu_mask, int64_t n, void* stream);
 int bdetr_p16_conv2d_bwd_data_masked_accum(const void* dy_bf16, const void* wt_bf16, float* dx, const uint64_t* relu_mask,
                                            const bdetr_conv_desc* d, void* stream);
 int bdetr_p16_conv2d_bwd_data_bnstats(const void* dy_bf16, const void* wt_bf16, float* dx,

@@ -234,3 +234,20 @@ def test_masked_skip_accumulate_in_the_bwd_data_epilogue(cuda, N, H, W, C, K):
     close(dx.view(rows, C), want, rtol=6e-5)
     masked = k.relu_mask_apply_(dev(d_out).view(rows, C), bits)
     assert torch.equal(masked.cpu().double(), d_out.double().reshape(rows, C) * on)
+
+
+@pytest.mark.parametrize("rows,C", [(800, 64), (3000, 256), (98, 2048)])
+def test_bn_apply_p16_with_the_shortcut_batchnorm_folded_in(cuda, rows, C):
+    """bdetr_bn_apply_p16(residual_p16 = 2): relu(bn(y) + bn_shortcut(y_shortcut)) in one pass is bit-identical to
+    normalising the projection shortcut first and adding it as an fp32 residual."""
+    from boosted_detr_amd import kernels as k
+    y, ys = dev(rnd(rows, C, seed=1) * 2 + 0.5), dev(rnd(rows, C, seed=2) * 3 - 0.2)
+    params = []
+    for t, seed in ((y, 3), (ys, 5)):
+        gamma, beta = dev(1 + 0.1 * rnd(C, seed=seed)), dev(0.1 * rnd(C, seed=seed + 1))
+        mean, rstd = k.bn_stats(rows, C, k.colstats(t), 1.001e-5, 0.99, True, dev(torch.zeros(C)), dev(torch.ones(C)), like=t)
+        params.append((mean, rstd, gamma, beta))
+    shortcut = k.bn_apply(ys, *params[1], None, False)
+    want32, wantf, wantb, wantm = k.bn_apply_p16(y, *params[0], shortcut, True, want_mask=True)
+    got32, gotf, gotb, gotm = k.bn_apply_p16(y, *params[0], ys, True, want_mask=True, residual_bn=params[1])
+    assert torch.equal(got32, want32) and torch.equal(gotf, wantf) and torch.equal(gotb, wantb) and torch.equal(gotm, wantm)
