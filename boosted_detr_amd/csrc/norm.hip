@@ -270,9 +270,8 @@ __global__ __launch_bounds__(256) void bn_apply_p16_kernel(const float* __restri
                                                            void* __restrict__ out_f16, void* __restrict__ out_bf16, unsigned long long* __restrict__ relu_mask,
                                                            int* __restrict__ overflow_flag, int64_t n4, int c4n) {
     // n4 is even and the stride is even: the two lanes of a pair (one 8-element group) always run together
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    auto body = [&](int64_t i, const f32x4 v) {
         const int c = (int)(i % c4n) * 4;
-        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
         const f32x4 m = *reinterpret_cast<const f32x4*>(mean + c), rs = *reinterpret_cast<const f32x4*>(rstd + c);
         const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c), b = *reinterpret_cast<const f32x4*>(beta + c);
         f32x4 o;
@@ -316,7 +315,17 @@ __global__ __launch_bounds__(256) void bn_apply_p16_kernel(const float* __restri
             }
         }
         if (out_bf16 != nullptr) p16_store4<false>(out_bf16, i, o[0], o[1], o[2], o[3]);
+    };
+    // Two row groups per trip with both x loads issued first (twice the bytes in flight per wave).  The trip count is decided
+    // per aligned 64-index group = per wave, so that the __ballot of a group always sees all of its lanes together.
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; (i | 63) + stride < n4; i += 2 * stride) {
+        const f32x4 v0 = reinterpret_cast<const f32x4*>(x)[i], v1 = reinterpret_cast<const f32x4*>(x)[i + stride];
+        body(i, v0);
+        body(i + stride, v1);
     }
+    for (; i < n4; i += stride) body(i, reinterpret_cast<const f32x4*>(x)[i]);
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_p16_kernel(const float* __restrict__ dout, const void* __restrict__ out, int out_p16, const float* __restrict__ x,
