@@ -32,10 +32,14 @@ __global__ __launch_bounds__(256) void colreduce2_kernel(F f, int64_t rows, int 
     const int64_t r1 = min(rows, r0 + rows_per_chunk);
     f32x4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
     if (c < C) {
-        for (int64_t r = r0 + ry; r < r1; r += ty) {
-            f32x4 qa, qb; f(r, c, qa, qb);
-            a += qa; b += qb;
+        // two rows per trip: both rows' loads are in flight before the first is consumed (same summation order)
+        int64_t r = r0 + ry;
+        for (; r + ty < r1; r += 2 * ty) {
+            f32x4 qa0, qb0, qa1, qb1;
+            f(r, c, qa0, qb0); f(r + ty, c, qa1, qb1);
+            a += qa0; b += qb0; a += qa1; b += qb1;
         }
+        if (r < r1) { f32x4 qa, qb; f(r, c, qa, qb); a += qa; b += qb; }
     }
     sa[tid] = a; sb[tid] = b;
     __syncthreads();
