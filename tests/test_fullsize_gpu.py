@@ -132,3 +132,46 @@ def test_config3_boosted_fashionpedia_batch2_matches_oracle(cuda):
         g, w = v.grad_numpy().astype(np.float64).ravel(), grads[name].astype(np.float64).ravel()
         cos = g @ w / (np.linalg.norm(g) * np.linalg.norm(w))
         assert cos > 0.995, (name, cos)
+
+
+def test_config5_resnet101_1333x800_300_queries_batch1_matches_oracle(cuda):
+    """BASELINE.json configs[4]'s detection path at full size: one 1333x800 image (odd feature-map sizes at every stride:
+    667, 334, 167, 84, 42 x 400 ... 25), ResNet-101, 6 + 6 layers, 300 queries, COCO-80 - forward outputs within 1e-3 of the
+    CPU oracle, class ids and match indices bit-exact, loss within 1e-3, gradient direction of four large tensors."""
+    from boosted_detr_amd import parameters, transformers
+    from boosted_detr_amd.backbone import RESNET101_STAGES
+    from boosted_detr_amd.model import DETR
+    from oracle import detr_oracle as O
+    size = (1333, 800)
+    cfg = O.Config(image_size=size, num_object_preds=300, num_encoder_blocks=6, num_decoder_blocks=6, num_categories=82, num_attributes=3,
+                   attribute_weight=0.0, stages=RESNET101_STAGES)
+    batch = O.make_batch(cfg, 1, 100, seed=77, num_objects=[23])
+    params = O.make_params(cfg, seed=2)
+    transformers.AttentionBlock.dropout_rate = 0.0
+    transformers.FeedForwardBlock.dropout_rate = 0.0
+    model = DETR(num_object_preds=300, image_size=size, num_encoder_blocks=6, num_encoder_heads=8, encoder_dim=256, num_decoder_blocks=6,
+                 num_decoder_heads=8, decoder_dim=256, num_panoptic_heads=1, panoptic_dim=32, vocab_dict=parameters.COCO_VOCAB,
+                 attribute_weight=0.0, backbone_name="ResNet101")
+    ren = lambda k: k.replace("EncoderBackbone/resnet50/", "EncoderBackbone/resnet101/")
+    model.forward_backward(batch)
+    model.set_weights_dict({ren(k): v for k, v in params.items()})
+    y = model.forward_backward(batch)
+    torch.cuda.synchronize()
+    out, grads = O.train_step_grads(cfg, params, batch, dtype=torch.float32)
+    for got, want in zip(y, (out.cat_preds, out.attribute_preds, out.box_preds)):
+        assert rel_err(got.cpu().numpy(), want.detach().numpy()) < 1e-3
+    assert np.array_equal(y[0].cpu().numpy().argmax(-1), out.cat_preds.detach().numpy().argmax(-1))
+    match = model.loss_fn.last_match.cpu().numpy()
+    want = -np.ones_like(match)
+    for b, (r, c) in enumerate(out.loss.matches):
+        want[b, r] = c
+    assert np.array_equal(match, want)
+    logs = model.logs_to_host(model.step_logs())
+    ref = float(out.loss_vector.detach().double().mean())
+    assert abs(logs["loss"] - ref) <= 1e-3 * abs(ref)
+    for name in ("EncoderBackbone/resnet50/conv4_block17_2_conv/kernel", "EncoderBackbone/resnet50/conv2_block1_0_conv/kernel",
+                 "ImageEncoderAttention/EncoderBlock_3/FeedForwardBlock/DenseRelu/kernel", "CategoryPredictionHead/DenseLogits/kernel"):
+        v = [x for x in model.variables if x.name == ren(name)][0]
+        g, w = v.grad_numpy().astype(np.float64).ravel(), grads[name].astype(np.float64).ravel()
+        cos = g @ w / (np.linalg.norm(g) * np.linalg.norm(w))
+        assert cos > 0.995, (name, cos)
