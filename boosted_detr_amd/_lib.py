@@ -39,7 +39,7 @@ class BnAffine(C.Structure):
 
 class BnBwdFuse(C.Structure):
     _fields_ = [("y", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("relu", C.c_int),
-                ("part_g", C.c_void_p), ("part_gx", C.c_void_p)]
+                ("part_g", C.c_void_p), ("part_gx", C.c_void_p), ("relu_mask", C.c_void_p)]
 
 
 class LossDesc(C.Structure):
@@ -87,7 +87,7 @@ SIGNATURES = {
     "bdetr_p16_conv2d_fwd": (I, [P, P, P, P, C.POINTER(ConvDesc), I, P, P, P]),
     "bdetr_p16_conv2d_bwd_data": (I, [P, P, P, C.POINTER(ConvDesc), I, P]),
     "bdetr_p16_conv2d_bwd_data_stat_chunks": (I, [C.POINTER(ConvDesc)]),
-    "bdetr_p16_conv2d_bwd_data_masked_accum": (I, [P, P, P, P, C.POINTER(ConvDesc), P]),
+    "bdetr_p16_conv2d_bwd_data_masked_accum": (I, [P, P, P, P, C.POINTER(ConvDesc), C.POINTER(BnBwdFuse), P]),
     "bdetr_relu_mask_apply": (I, [P, P, C.c_int64, P]),
     "bdetr_p16_conv2d_bwd_data_bnstats": (I, [P, P, P, C.POINTER(ConvDesc), C.POINTER(BnBwdFuse), P]),
     "bdetr_p16_conv2d_bwd_weight_splitk": (I, [C.POINTER(ConvDesc)]),

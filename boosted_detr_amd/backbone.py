@@ -37,12 +37,14 @@ class _ConvBN(Layer):
         self.bn = ops.BNState(gamma, beta, mm, mv, RESNET_BN_EPS)
         self.built = True
 
-    def call(self, inputs, training=False, relu=True, residual=None, x_needs_grad=True, want_fp32=True, want_p16=False, defer_apply=False):
+    def call(self, inputs, training=False, relu=True, residual=None, x_needs_grad=True, want_fp32=True, want_p16=False, defer_apply=False,
+             next_is_identity_unit=False):
         x = inputs[0]
         # S18: BN uses batch statistics only when training AND the layer is trainable
         return ops.conv_bn(x, self.kernel, self.bias, self.bn, self.stride, self.pad, relu, residual=residual,
                            training=training, bn_batch_stats=training and self.trainable, x_needs_grad=x_needs_grad,
-                           want_fp32=want_fp32, want_p16=want_p16, defer_apply=defer_apply)
+                           want_fp32=want_fp32, want_p16=want_p16, defer_apply=defer_apply,
+                           sole_consumer_is_identity_unit=next_is_identity_unit)
 
 
 class ResNet(Layer):
@@ -87,7 +89,9 @@ class ResNet(Layer):
             sc = blk["short"]([x], training=training, relu=False, defer_apply=True) if blk["short"] is not None else x
             y = blk["c1"]([x], training=training, relu=True, want_fp32=False, want_p16=True)
             y = blk["c2"]([y], training=training, relu=True, want_fp32=False, want_p16=True)
-            x = blk["c3"]([y], training=training, relu=True, residual=sc, want_fp32=last, want_p16=not last)     # BN -> Add([shortcut, x]) -> ReLU
+            nxt_identity = not last and self.blocks[i + 1]["short"] is None       # the next unit reads x through its c1 and its identity skip only
+            x = blk["c3"]([y], training=training, relu=True, residual=sc, want_fp32=last, want_p16=not last,
+                          next_is_identity_unit=nxt_identity)                                 # BN -> Add([shortcut, x]) -> ReLU
         return x
 
 

@@ -34,6 +34,7 @@ struct GemmParams {
     // that would re-read C and y (colreduce2<BnBwdFn>) disappears.  bnb_y has C's shape and leading dimension.
     const float* bnb_y; const float* bnb_mean; const float* bnb_rstd; const float* bnb_gamma; const float* bnb_beta;
     int bnb_relu; float* bnb_sum_g; float* bnb_sum_gx;
+    const unsigned long long* bnb_mask;      // (sgemm's persistent dense kernels) the ReLU decision comes from these bits, not from recomputing it
     // ST_ACCUM with acc_mask set (sgemm's persistent dense kernels only): C = product + C * bit, bit = bn_apply_p16's 1-bit
     // ReLU mask of the element (norm.hip relu_mask_bits4 layout) - the skip branch of a residual unit merged without ever
     // materialising its masked gradient

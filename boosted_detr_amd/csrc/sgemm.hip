@@ -285,33 +285,49 @@ __device__ __forceinline__ void direct_epilogue(f32x16 (&acc)[BM / WM / 32][BN /
     }
     if (g.bnb_y != nullptr) {
         // fused BatchNorm-backward sums of g = C * [y' > 0] and g * xhat per column, straight from the accumulator
-        // layout (a lane owns a column); one partial row per (tile_i, wm)
-        const __amdgpu_buffer_rsrc_t rsY = tile_rsrc(g.bnb_y);
+        // layout (a lane owns a column); one partial row per (tile_i, wm).  The ReLU decision is recomputed from y (no
+        // residual) or read from the unit's bit mask (residual units); two complete copies, see the note above.
+        auto bn_sums = [&](auto bits_c) {
+            constexpr bool BITS = decltype(bits_c)::value;
+            const __amdgpu_buffer_rsrc_t rsY = tile_rsrc(g.bnb_y);
+            const __amdgpu_buffer_rsrc_t rsB = make_rsrc(g.bnb_mask, BITS ? (unsigned)(((int64_t)g.I * g.ldc + 255) >> 8) * 32u : 0u);
 #pragma unroll
-        for (int b = 0; b < TN; ++b) {
-            const int j = jl + b * 32;
-            const bool jok = j < g.J;
-            const float bm = jok ? g.bnb_mean[j] : 0.f, brs = jok ? g.bnb_rstd[j] : 0.f, bgm = jok ? g.bnb_gamma[j] : 0.f, bbt = jok ? g.bnb_beta[j] : 0.f;
-            float yv[TM][16];
-            for_rows([&](int a, int e, unsigned ro) { yv[a][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsY, vcol[b] + ro, 0, 0)); });
-            float sg = 0.f, sgx = 0.f;
+            for (int b = 0; b < TN; ++b) {
+                const int j = jl + b * 32;
+                const bool jok = j < g.J;
+                const float bm = jok ? g.bnb_mean[j] : 0.f, brs = jok ? g.bnb_rstd[j] : 0.f, bgm = jok ? g.bnb_gamma[j] : 0.f, bbt = jok ? g.bnb_beta[j] : 0.f;
+                float yv[TM][16];
+                unsigned keep[TM][16];
+                for_rows([&](int a, int e, unsigned ro) {
+                    yv[a][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsY, vcol[b] + ro, 0, 0));
+                    if constexpr (BITS) {
+                        const unsigned n = (unsigned)(i0 + wm * WTM + 4 * lh + a * 32 + (e & 3) + 8 * (e >> 2)) * (unsigned)g.ldc + (unsigned)j;
+                        const unsigned wo = vcol[b] == FAR ? OOB : ((((n >> 8) << 2) | (n & 3u)) << 3) + ((n >> 5) & 4u);
+                        keep[a][e] = (__builtin_amdgcn_raw_buffer_load_b32(rsB, wo, 0, 0) >> ((n >> 2) & 31u)) & 1u;
+                    }
+                });
+                float sg = 0.f, sgx = 0.f;
 #pragma unroll
-            for (int a = 0; a < TM; ++a)
+                for (int a = 0; a < TM; ++a)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const bool in = wm * WTM + 4 * lh + a * 32 + (e & 3) + 8 * (e >> 2) < rows_here;
-                    const bool on = in && (!g.bnb_relu || (__builtin_fmaf(yv[a][e] - bm, brs * bgm, bbt) > 0.f));      // = norm.hip's bn_affine
-                    const float ge = on ? acc[a][b][e] : 0.f;
-                    sg += ge; sgx += ge * ((yv[a][e] - bm) * brs);
+                    for (int e = 0; e < 16; ++e) {
+                        const bool in = wm * WTM + 4 * lh + a * 32 + (e & 3) + 8 * (e >> 2) < rows_here;
+                        bool on;
+                        if constexpr (BITS) on = in && keep[a][e] != 0u;
+                        else on = in && (!g.bnb_relu || (__builtin_fmaf(yv[a][e] - bm, brs * bgm, bbt) > 0.f));      // = norm.hip's bn_affine
+                        const float ge = on ? acc[a][b][e] : 0.f;
+                        sg += ge; sgx += ge * ((yv[a][e] - bm) * brs);
+                    }
+                sg += __shfl_xor(sg, 32, 64);
+                sgx += __shfl_xor(sgx, 32, 64);
+                if (lh == 0 && jok) {
+                    const int64_t chunk = (int64_t)tile_i * WM + wm;
+                    g.bnb_sum_g[chunk * g.J + j] = sg;
+                    g.bnb_sum_gx[chunk * g.J + j] = sgx;
                 }
-            sg += __shfl_xor(sg, 32, 64);
-            sgx += __shfl_xor(sgx, 32, 64);
-            if (lh == 0 && jok) {
-                const int64_t chunk = (int64_t)tile_i * WM + wm;
-                g.bnb_sum_g[chunk * g.J + j] = sg;
-                g.bnb_sum_gx[chunk * g.J + j] = sgx;
             }
-        }
+        };
+        if (g.bnb_mask != nullptr) bn_sums(std::true_type{}); else bn_sums(std::false_type{});
     }
     if (g.dbg & 1) return;
     for_rows([&](int a, int e, unsigned ro) {
@@ -796,11 +812,14 @@ static int p16_bwd_data(const void* dy_bf16, const void* wt_bf16, float* dx, con
     g.c = dx; g.ldc = d->C; g.mode = accumulate ? ST_ACCUM : ST_STORE;
     g.acc_mask = reinterpret_cast<const unsigned long long*>(acc_mask);
     if (bn != nullptr) {
-        BDETR_CHECK_ARG(!accumulate && d->stride == 1 && d->C % 4 == 0 && aligned16(dx) && aligned16(bn->y),
-                        "bdetr_p16_conv2d_bwd_data_bnstats: needs a plain store of 16-byte aligned rows (no accumulate, stride 1)");
+        const bool dense11 = d->R == 1 && d->S == 1 && d->pad == 0 && d->stride == 1;      // the persistent kernels' register epilogue
+        BDETR_CHECK_ARG((!accumulate || dense11) && d->stride == 1 && d->C % 4 == 0 && aligned16(dx) && aligned16(bn->y),
+                        "bdetr_p16_conv2d_bwd_data_bnstats: needs 16-byte aligned rows, stride 1, and a plain store unless the conv is 1x1");
+        BDETR_CHECK_ARG(bn->relu_mask == nullptr || dense11, "bdetr_p16_conv2d_bwd_data_bnstats: a bit-mask ReLU decision needs a 1x1 stride-1 conv");
         BDETR_CHECK_ARG(bn->y && bn->mean && bn->rstd && bn->gamma && bn->beta && bn->part_g && bn->part_gx, "bdetr_p16_conv2d_bwd_data_bnstats: null pointer");
         g.bnb_y = bn->y; g.bnb_mean = bn->mean; g.bnb_rstd = bn->rstd; g.bnb_gamma = bn->gamma; g.bnb_beta = bn->beta;
         g.bnb_relu = bn->relu; g.bnb_sum_g = bn->part_g; g.bnb_sum_gx = bn->part_gx;
+        g.bnb_mask = reinterpret_cast<const unsigned long long*>(bn->relu_mask);
     }
     if (d->R == 1 && d->S == 1 && d->pad == 0) {
         g.I = M; g.J = d->C; g.R = d->K;
@@ -830,11 +849,11 @@ extern "C" int bdetr_p16_conv2d_bwd_data(const void* dy_bf16, const void* wt_bf1
     return p16_bwd_data(dy_bf16, wt_bf16, dx, d, accumulate, nullptr, nullptr, stream);
 }
 extern "C" int bdetr_p16_conv2d_bwd_data_masked_accum(const void* dy_bf16, const void* wt_bf16, float* dx, const uint64_t* relu_mask,
-                                                      const bdetr_conv_desc* d, void* stream) {
+                                                      const bdetr_conv_desc* d, const bdetr_bn_bwd_fuse* bn, void* stream) {
     BDETR_CHECK_ARG(relu_mask != nullptr && d != nullptr && d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0,
                     "bdetr_p16_conv2d_bwd_data_masked_accum: 1x1 stride-1 convolutions only, mask required");
     BDETR_CHECK_ARG((int64_t)d->N * d->H * d->W * d->C < (1LL << 32), "bdetr_p16_conv2d_bwd_data_masked_accum: more than 2^32 elements");
-    return p16_bwd_data(dy_bf16, wt_bf16, dx, d, 1, nullptr, relu_mask, stream);
+    return p16_bwd_data(dy_bf16, wt_bf16, dx, d, 1, bn, relu_mask, stream);
 }
 extern "C" int bdetr_p16_conv2d_bwd_data_bnstats(const void* dy_bf16, const void* wt_bf16, float* dx,
                                                  const bdetr_conv_desc* d, const bdetr_bn_bwd_fuse* bn, void* stream) {

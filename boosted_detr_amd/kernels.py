@@ -365,15 +365,30 @@ def relu_mask_apply_(x: torch.Tensor, relu_mask: torch.Tensor) -> torch.Tensor:
     return x
 
 
-def p16_conv2d_bwd_data_masked_accum(dy_bf16, wt_bf16, g: ConvGeom, dx: torch.Tensor, relu_mask: torch.Tensor):
+def p16_conv2d_bwd_data_masked_accum(dy_bf16, wt_bf16, g: ConvGeom, dx: torch.Tensor, relu_mask: torch.Tensor, bn_ctx=None):
     """dx (the gradient of a residual unit's output on entry) <- conv_transpose(dy) + dx * relu_mask, in place: the unit's skip
-    branch merged inside the 1x1 backward-data epilogue of its first convolution."""
+    branch merged inside the 1x1 backward-data epilogue of its first convolution.  bn_ctx = (y_prev, mean, rstd, gamma, beta,
+    relu_mask_prev): the result is the complete output gradient of the PREVIOUS residual unit - also emit that unit's
+    BatchNorm-backward partial sums; returns (dx, (part_g, part_gx, nparts)) then."""
     _chk(dy_bf16, wt_bf16, dx)
     _chk(relu_mask, dtype=torch.int64)
+    L = _lib.lib()
     d = g.desc()
-    check(_lib.lib().bdetr_p16_conv2d_bwd_data_masked_accum(_p(dy_bf16), _p(wt_bf16), _p(dx), _p(relu_mask), C.byref(d), _stream()),
+    if bn_ctx is None:
+        check(L.bdetr_p16_conv2d_bwd_data_masked_accum(_p(dy_bf16), _p(wt_bf16), _p(dx), _p(relu_mask), C.byref(d), None, _stream()),
+              "p16_conv2d_bwd_data_masked_accum")
+        return dx
+    y_prev, mean, rstd, gamma, beta, bits_prev = bn_ctx
+    _chk(y_prev, mean, rstd, gamma, beta)
+    _chk(bits_prev, dtype=torch.int64)
+    n = L.bdetr_p16_conv2d_bwd_data_stat_chunks(C.byref(d))
+    if n <= 0:
+        check(-1, "p16_conv2d_bwd_data_stat_chunks")
+    pg, pgx = empty(n, g.C, like=dy_bf16), empty(n, g.C, like=dy_bf16)
+    f = BnBwdFuse(_p(y_prev), _p(mean), _p(rstd), _p(gamma), _p(beta), 1, _p(pg), _p(pgx), _p(bits_prev))
+    check(L.bdetr_p16_conv2d_bwd_data_masked_accum(_p(dy_bf16), _p(wt_bf16), _p(dx), _p(relu_mask), C.byref(d), C.byref(f), _stream()),
           "p16_conv2d_bwd_data_masked_accum")
-    return dx
+    return dx, (pg, pgx, n)
 
 
 def p16_conv2d_bwd_data_bnstats(dy_bf16, wt_bf16, g: ConvGeom, y_prev, mean, rstd, gamma, beta, relu: bool):
@@ -387,7 +402,7 @@ def p16_conv2d_bwd_data_bnstats(dy_bf16, wt_bf16, g: ConvGeom, y_prev, mean, rst
     if n <= 0:
         check(-1, "p16_conv2d_bwd_data_stat_chunks")
     pg, pgx = empty(n, g.C, like=dy_bf16), empty(n, g.C, like=dy_bf16)
-    f = BnBwdFuse(_p(y_prev), _p(mean), _p(rstd), _p(gamma), _p(beta), int(relu), _p(pg), _p(pgx))
+    f = BnBwdFuse(_p(y_prev), _p(mean), _p(rstd), _p(gamma), _p(beta), int(relu), _p(pg), _p(pgx), None)
     check(L.bdetr_p16_conv2d_bwd_data_bnstats(_p(dy_bf16), _p(wt_bf16), _p(dx), C.byref(d), C.byref(f), _stream()), "p16_conv2d_bwd_data_bnstats")
     return dx, (pg, pgx, n)
 

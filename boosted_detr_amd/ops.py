@@ -225,9 +225,13 @@ def packed_weights(w: Variable, need_bwd: bool = True):
 
 def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int, pad: int, relu: bool,
             residual: Optional[torch.Tensor] = None, training: bool = False, bn_batch_stats: Optional[bool] = None,
-            x_needs_grad: bool = True, want_fp32: bool = True, want_p16: bool = False, defer_apply: bool = False) -> torch.Tensor:
+            x_needs_grad: bool = True, want_fp32: bool = True, want_p16: bool = False, defer_apply: bool = False,
+            sole_consumer_is_identity_unit: bool = False) -> torch.Tensor:
     """Conv2D(+bias) -> BatchNormalization -> [+ residual] -> [ReLU]  (keras ResNet-50 block unit).
 
+    sole_consumer_is_identity_unit (residual units): the only consumers of this output are the next unit's first 1x1
+    convolution and its identity skip - the masked accumulate that completes this output's gradient there can then also do
+    THIS unit's BatchNorm-backward reduction (ctx attached to the handle as `_bn_ctx_bits`).
     defer_apply (projection shortcut, no ReLU, no residual; P16 path only): the statistics are reduced but the normalised
     tensor is not written - the returned handle is the RAW convolution output tagged `_deferred_bn`, and the unit that takes
     it as `residual` applies both BatchNorms in its one pass (bn_apply_p16 residual_bn; as_fp32 is the fallback).
@@ -269,6 +273,8 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
             out = (o32 if fp32_out else of).view(N, g.OH, g.OW, Kout)
         if want_p16:
             out._p16f, out._p16b, out._p16_only = of.view(out.shape), ob.view(out.shape), not fp32_out
+        if relu_bits is not None and sole_consumer_is_identity_unit and os.environ.get("BDETR_BN_FUSE", "1") != "0":
+            out._bn_ctx_bits = (y2d, mean, rstd, bn.gamma.value, bn.beta.value, relu_bits)
         if not fp32_out and residual is None and os.environ.get("BDETR_BN_FUSE", "1") != "0":
             # a link with exactly one consumer (the next conv of the bottleneck): that conv's backward-data epilogue can do
             # THIS BatchNorm's backward reduction while it stores the gradient (ops: see `backward` below)
@@ -332,7 +338,12 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
                 if acc is not None and acc[0] is not None:
                     skip_bits = getattr(acc[0], "_lazy_mask", None)
                     if skip_bits is not None and R == 1 and S == 1 and stride == 1 and pad == 0:
-                        K.p16_conv2d_bwd_data_masked_accum(dyb4, wt, g, acc[0].view(N, H, W, Cin), skip_bits)
+                        ctx_bits = getattr(x_handle, "_bn_ctx_bits", None)
+                        if ctx_bits is not None:        # this merge completes the previous unit's output gradient: do its BN-backward sums too
+                            _, parts = K.p16_conv2d_bwd_data_masked_accum(dyb4, wt, g, acc[0].view(N, H, W, Cin), skip_bits, bn_ctx=ctx_bits)
+                            acc[0]._bnb_parts = parts
+                        else:
+                            K.p16_conv2d_bwd_data_masked_accum(dyb4, wt, g, acc[0].view(N, H, W, Cin), skip_bits)
                         del acc[0]._lazy_mask
                     else:
                         K.p16_conv2d_bwd_data(dyb4, wt, g, dx=materialise(acc[0]).view(N, H, W, Cin), accumulate=True)

@@ -191,6 +191,7 @@ int bdetr_p16_conv2d_bwd_data(const void* dy_bf16, const void* wt_bf16, float* d
 typedef struct {
     const float* y; const float* mean; const float* rstd; const float* gamma; const float* beta; int relu;
     float* part_g; float* part_gx;
+    const uint64_t* relu_mask;      /* may be null; else out = relu(bn(y) + shortcut): the ReLU decision is bdetr_bn_apply_p16's bit mask (1x1 convs only) */
 } bdetr_bn_bwd_fuse;
 int bdetr_p16_conv2d_bwd_data_stat_chunks(const bdetr_conv_desc* d);
 /* x <- x * relu_mask in place (n elements, n % 4 == 0): materialises a gradient that was handed on with its unit's ReLU mask
@@ -201,7 +202,8 @@ int bdetr_relu_mask_apply(float* x, const uint64_t* relu_mask, int64_t n, void* 
  * bdetr_bn_apply_p16 wrote for that unit.  The masked gradient of the skip branch (Keras: the Add + Activation of
  * keras.applications.resnet block1, reference backbone.py:37-38) is never materialised. */
 int bdetr_p16_conv2d_bwd_data_masked_accum(const void* dy_bf16, const void* wt_bf16, float* dx, const uint64_t* relu_mask,
-                                           const bdetr_conv_desc* d, void* stream);
+                                           const bdetr_conv_desc* d, const bdetr_bn_bwd_fuse* bn /* may be null: the BatchNorm-backward
+                                           sums of the unit whose output gradient this launch completes */, void* stream);
 int bdetr_p16_conv2d_bwd_data_bnstats(const void* dy_bf16, const void* wt_bf16, float* dx,
                                       const bdetr_conv_desc* d, const bdetr_bn_bwd_fuse* bn, void* stream);
 /* dw fp32 [K][R][S][C] += sum over pixels of dy x patches(x); with splitk > 1 the slices add with float

@@ -251,3 +251,35 @@ def test_bn_apply_p16_with_the_shortcut_batchnorm_folded_in(cuda, rows, C):
     want32, wantf, wantb, wantm = k.bn_apply_p16(y, *params[0], shortcut, True, want_mask=True)
     got32, gotf, gotb, gotm = k.bn_apply_p16(y, *params[0], ys, True, want_mask=True, residual_bn=params[1])
     assert torch.equal(got32, want32) and torch.equal(gotf, wantf) and torch.equal(gotb, wantb) and torch.equal(gotm, wantm)
+
+
+@pytest.mark.parametrize("N,H,W,C,K", [(2, 20, 20, 64, 256), (3, 9, 11, 256, 64), (16, 40, 40, 1024, 256)])
+def test_masked_accumulate_also_reduces_the_previous_units_batchnorm_backward(cuda, N, H, W, C, K):
+    """bdetr_p16_conv2d_bwd_data_masked_accum with a BatchNorm context: the launch that completes a residual unit's output
+    gradient (product + skip gradient * this unit's mask) also emits the partial sums of the PREVIOUS unit's closing
+    BatchNorm (ReLU decision from that unit's bit mask).  dx is bit-identical to the plain masked accumulate, and bn_bwd_p16 fed
+    with the partials agrees with its own two-pass reduction (summation order: 1e-5)."""
+    from boosted_detr_amd import kernels as k
+    g = k.ConvGeom(N, H, W, C, K, 1, 1, 1, 0)
+    rows = N * H * W
+
+    def unit(seed):          # a residual unit's closing BatchNorm: conv output y, its statistics, the ReLU bit mask of relu(bn(y) + shortcut)
+        y = dev(rnd(rows, C, seed=seed) * 2 + 0.3)
+        gamma, beta = dev(1 + 0.1 * rnd(C, seed=seed + 1)), dev(0.1 * rnd(C, seed=seed + 2))
+        mean, rstd = k.bn_stats(rows, C, k.colstats(y), 1.001e-5, 0.99, True, dev(torch.zeros(C)), dev(torch.ones(C)), like=y)
+        _, _, _, bits = k.bn_apply_p16(y, mean, rstd, gamma, beta, dev(rnd(rows, C, seed=seed + 3)), True, want_fp32=False, want_f16=True,
+                                       want_bf16=False, want_mask=True)
+        return y, mean, rstd, gamma, beta, bits
+
+    prev, this = unit(10), unit(20)
+    d_out = rnd(N, H, W, C, seed=5)
+    _, wt = k.p16_pack_conv_weights(dev(rnd(K, 1, 1, C, seed=6, scale=C ** -0.5)), want_fwd=False)
+    _, dyb = k.p16_pack(dev(rnd(N, H, W, K, seed=7)), want_f16=False)
+    plain = k.p16_conv2d_bwd_data_masked_accum(dyb, wt, g, dev(d_out), this[5])
+    dx, parts = k.p16_conv2d_bwd_data_masked_accum(dyb, wt, g, dev(d_out), this[5], bn_ctx=prev)
+    assert torch.equal(dx, plain)
+    y, mean, rstd, gamma, beta, bits = prev
+    ref = k.bn_bwd_p16(dx.view(rows, C), bits, y, mean, rstd, gamma, True, False, beta=beta, want_fp32=True, out_p16=2)
+    got = k.bn_bwd_p16(dx.view(rows, C), bits, y, mean, rstd, gamma, True, False, beta=beta, want_fp32=True, out_p16=2, pre=parts)
+    close(got[2], ref[2], rtol=1e-5); close(got[3], ref[3], rtol=1e-5)          # dgamma, dbeta
+    close(got[1], ref[1], rtol=1e-5)                                             # dx of the BatchNorm

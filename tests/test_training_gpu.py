@@ -294,10 +294,11 @@ def test_graph_replayed_steps_equal_eager_steps(cuda):
         runs[graph] = (losses, m.get_weights_dict())
     le, lg = runs[False][0], runs[True][0]
     assert all(np.isfinite(lg))
-    # Two model instances already differ at rounding level after one step (atomics order; which gradients land directly in
-    # the flat buffer), and this 2-image toy amplifies a 5e-7 difference of the second loss to 2e-4 of the third (measured:
-    # consecutive eager instances alternate between two such trajectories).  Same numbers while that is still rounding noise:
-    assert all(abs(a - b) <= 1e-5 * abs(a) for a, b in zip(le[:2], lg[:2])), (le, lg)
+    # Two model instances already differ after one step (float atomics of the split-K weight gradients, which gradients
+    # land directly in the flat buffer): measured over ten EAGER instances the second loss takes a handful of values within
+    # 3e-5 of each other (113.5985 ... 113.6023), and this 2-image toy amplifies that to 4e-4 of the third.  Same numbers
+    # while that is still noise of that size:
+    assert all(abs(a - b) <= 1e-4 * abs(a) for a, b in zip(le[:2], lg[:2])), (le, lg)
     assert all(abs(a - b) <= 3e-3 * abs(a) for a, b in zip(le[:4], lg[:4])), (le, lg)
     assert all(abs(a - b) <= 5e-2 * abs(a) for a, b in zip(le, lg)), (le, lg)
     assert lg[2] != lg[4]                                                                    # fresh masks / inputs per replay, not a frozen step
