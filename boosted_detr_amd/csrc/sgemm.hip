@@ -339,6 +339,41 @@ __device__ __forceinline__ void direct_epilogue(f32x16 (&acc)[BM / WM / 32][BN /
     });
 }
 
+// Epilogue of the split-K weight-gradient kernels: float atomics straight from the accumulators with the addressing of
+// direct_epilogue (per-tile descriptor, running row offset, one add per atomic).  The generic per-element path spent ~85
+// VALU instructions on 64-bit address arithmetic per atomic - more than the atomic unit's own issue interval.
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void atomic_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], const GemmParams& g, int i0, int j0) {
+    constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
+    constexpr unsigned FAR = 0x80000000u;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN, li = lane & 31, lh = lane >> 5;
+    const unsigned ldc4 = (unsigned)g.ldc * 4u;
+    const int rows_here = min(BM, g.I - i0);
+    const unsigned long long p = reinterpret_cast<unsigned long long>(g.c) + (unsigned long long)i0 * ldc4;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p), hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
+                                                                         __builtin_amdgcn_readfirstlane(rows_here * (int)ldc4), 0x00020000);
+    unsigned vcol[TN];
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int j = j0 + wn * WTN + b * 32 + li;
+        vcol[b] = j < g.J ? (unsigned)(wm * WTM + 4 * lh) * ldc4 + (unsigned)j * 4u : FAR;
+    }
+    unsigned ro = 0;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const float v = g.alpha * acc[a][b][e];          // (a scalar copy: see direct_epilogue)
+                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, rsC, vcol[b] + ro, 0, 0);
+            }
+            ro += (e & 3) == 3 ? 5u * ldc4 : ldc4;
+        }
+}
+
 // NS = LDS stages: the loads of K-step t + NS - 1 are issued while K-step t computes and a counted s_waitcnt
 // vmcnt leaves the younger stages in flight across the (raw) barrier.
 constexpr int default_occ(int bm, int bn, int wm, int wn, int ns) { return (wm * wn == 4 && 2 * lds_bytes_for(bm, bn, ns) <= 160 * 1024) ? 2 : (wm * wn == 8 ? 2 : 1); }
@@ -625,6 +660,10 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
             }
         }
         fold_acc2();
+        if (XX && g.mode == ST_ATOMIC && g.bias == nullptr && g.act == BDETR_ACT_NONE && g.stat_sum == nullptr && !g.rowmap && g.ldc * 4 * BM < (1ll << 31)) {
+            atomic_epilogue<BM, BN, WM, WN>(acc, g, i0, j0);
+            return;
+        }
         gemm_epilogue<BM, BN, WM, WN, NT, LDS_BYTES / 4>(acc, g, reinterpret_cast<float*>(lds), tile_i, i0, j0, g.c, bias_pre);
     }
 }
