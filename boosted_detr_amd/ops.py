@@ -454,7 +454,7 @@ def dense(x: torch.Tensor, w: Variable, b: Variable, act: int = K.ACT_NONE) -> t
     y2d = K.linear_fwd(x2d, w.value, b.value, act)
     y = y2d.view(*x.shape[:-1], w.value.shape[0])
 
-    def backward(g_out):
+    def backward(g_out, acc=None):
         g2d = _2d(g_out.contiguous())
         if act == K.ACT_RELU:
             g2d = K.relu_bwd(y2d, g2d)
@@ -470,8 +470,14 @@ def dense(x: torch.Tensor, w: Variable, b: Variable, act: int = K.ACT_NONE) -> t
                     s = GradSink(b)
                     K.colsum(g2d, out=s.buf, prezeroed=s.mode == "direct")
                     s.commit()
+        have = acc[0] if acc is not None else None
+        if have is not None and have.is_contiguous() and have.shape == x.shape:
+            # another consumer's gradient of x is already there: add into it in the GEMM epilogue (no separate axpy pass)
+            K.linear_bwd_data(g2d, w.value, dx=_2d(materialise(have)), accumulate=True)
+            return (have,)
         return (_own(K.linear_bwd_data(g2d, w.value).view(x.shape)),)
 
+    backward.wants_acc = True
     _rec([y], [x], backward)
     return y
 
