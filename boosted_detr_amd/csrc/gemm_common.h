@@ -39,7 +39,7 @@ struct GemmParams {
     // ReLU mask of the element (norm.hip relu_mask_bits4 layout) - the skip branch of a residual unit merged without ever
     // materialising its masked gradient
     const unsigned long long* acc_mask;
-    int dbg;
+    int dbg;                            // diagnostic builds of a launch (sgemm.hip, BDETR_SGEMM_DBG; tools/epi_probe.py): 1 = no C stores, 2 = no K loop, 4 = per-element stores; 0 in production
 };
 
 inline void init_params(GemmParams& g) {
