@@ -493,6 +493,7 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
     };
     constexpr int NLOAD = NIA + NIB;
     auto issue_all = [&](int buf, int r0) {
+        if (g.dbg & 16) return;                          // diagnostic: no staging loads
         [&]<int... L>(std::integer_sequence<int, L...>) { (issue_one(buf, r0, std::integral_constant<int, L>{}), ...); }(std::make_integer_sequence<int, NLOAD>{});
         if constexpr (!XX) { LA::step_next(opa, stA); LB::step_next(opb, stB); }
         else {
@@ -566,6 +567,7 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
     // issue cost (address VALU + M0 + buffer_load ... lds) then hides in the shadow of the preceding MFMAs instead of
     // running as a serial preamble in front of them.
     auto kstep = [&](int buf) {
+        if (g.dbg & 8) return;                           // diagnostic: no fragment reads / MFMAs
         const unsigned char* tA = lds + buf * STAGE_BYTES;
         const unsigned char* tB = tA + A_BYTES;
 #pragma unroll
