@@ -89,6 +89,7 @@ SIGNATURES = {
     "bdetr_p16_conv2d_bwd_data_stat_chunks": (I, [C.POINTER(ConvDesc)]),
     "bdetr_p16_conv2d_bwd_data_masked_accum": (I, [P, P, P, P, C.POINTER(ConvDesc), C.POINTER(BnBwdFuse), P]),
     "bdetr_relu_mask_apply": (I, [P, P, C.c_int64, P]),
+    "bdetr_sgemm_debug_stamps": (I, [P, I]),
     "bdetr_p16_conv2d_bwd_data_bnstats": (I, [P, P, P, C.POINTER(ConvDesc), C.POINTER(BnBwdFuse), P]),
     "bdetr_p16_conv2d_bwd_weight_splitk": (I, [C.POINTER(ConvDesc)]),
     "bdetr_p16_conv2d_bwd_weight": (I, [P, P, P, C.POINTER(ConvDesc), I, P]),

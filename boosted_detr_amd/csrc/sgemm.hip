@@ -176,6 +176,8 @@ struct XXPatch {
 // ----------------------------------------------------------------------------------------
 __device__ __forceinline__ int xx_swz(int r) { return ((r & 1) << 3) | ((r >> 1) & 1); }
 
+__device__ unsigned long long g_stamps[64];      // diagnostic cycle stamps (BDETR_SGEMM_DBG bit 32)
+
 constexpr int lds_bytes_for(int bm, int bn, int ns) { return ns * (bm + bn) * 128 > bm * bn * 4 ? ns * (bm + bn) * 128 : bm * bn * 4; }
 
 // Epilogue of the persistent RR kernels: the C tile goes from the accumulators straight to memory, one dword per lane
@@ -651,6 +653,29 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
         float bias_pre[TN];
         gemm_load_bias<BM, BN, WM, WN>(g, j0, bias_pre);              // lands during the K loop
         if (nk > 0) issue_all(0, r_begin);
+        if ((g.dbg & 32) && blockIdx.x == 1 && blockIdx.z == 0 && wave == 0) {
+            // diagnostic: cycle stamps of workgroup 1's first wave over its first 12 K-steps (bdetr_sgemm_debug_stamps):
+            // per step {after the load wait, after the barrier, after issuing the next stage, after issuing the MFMAs}
+            unsigned long long st[48];
+            auto stamp = [&](int i) { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); st[i] = t; };
+#pragma unroll
+            for (int kt = 0; kt < 12; ++kt) {
+                if (kt < nk) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(4 * kt);
+                    asm volatile("s_barrier" ::: "memory"); stamp(4 * kt + 1);
+                    if (kt + 1 < nk) issue_all((kt + 1) & 1, r_begin + (kt + 1) * BK);
+                    stamp(4 * kt + 2);
+                    kstep(kt & 1);
+                    stamp(4 * kt + 3);
+                }
+            }
+            for (int kt = 12; kt < nk; ++kt) {
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                if (kt + 1 < nk) issue_all((kt + 1) & 1, r_begin + (kt + 1) * BK);
+                kstep(kt & 1);
+            }
+            if (lane == 0) for (int i = 0; i < 48; ++i) g_stamps[i] = st[i];
+        } else
         for (int kt = 0; kt < nk; kt += 2) {
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             if (kt + 1 < nk) issue_all(1, r_begin + (kt + 1) * BK);
@@ -788,6 +813,14 @@ bool is_1x1_dense(const bdetr_conv_desc* d) { return d->R == 1 && d->S == 1 && d
 // ----------------------------------------------------------------------------------------
 // C ABI
 // ----------------------------------------------------------------------------------------
+// diagnostic: the cycle stamps a launch made with BDETR_SGEMM_DBG bit 32 left behind (tools/kstep_stamps.py)
+extern "C" int bdetr_sgemm_debug_stamps(uint64_t* out, int n) {
+    BDETR_CHECK_ARG(out && n > 0 && n <= 64, "bdetr_sgemm_debug_stamps: 1 <= n <= 64");
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(uint64_t) * (size_t)n);
+    if (e != hipSuccess) { bdetr_set_error("bdetr_sgemm_debug_stamps: %s", hipGetErrorString(e)); return (int)e; }
+    return 0;
+}
+
 extern "C" int bdetr_p16_supported(const bdetr_conv_desc* d) {
     if (!d || d->C % 8 || d->K % 8) return 0;
     if (!(d->R == 1 && d->S == 1) && d->C % BK) return 0;

@@ -194,6 +194,8 @@ typedef struct {
     const uint64_t* relu_mask;      /* may be null; else out = relu(bn(y) + shortcut): the ReLU decision is bdetr_bn_apply_p16's bit mask (1x1 convs only) */
 } bdetr_bn_bwd_fuse;
 int bdetr_p16_conv2d_bwd_data_stat_chunks(const bdetr_conv_desc* d);
+/* diagnostic (BDETR_SGEMM_DBG bit 32): cycle stamps of one workgroup's first K-steps; see tools/kstep_stamps.py */
+int bdetr_sgemm_debug_stamps(uint64_t* out, int n);
 /* x <- x * relu_mask in place (n elements, n % 4 == 0): materialises a gradient that was handed on with its unit's ReLU mask
  * still to be applied, for consumers other than bdetr_p16_conv2d_bwd_data_masked_accum / bdetr_bn_bwd_p16(out_p16 = 2). */
 int bdetr_relu_mask_apply(float* x, const uint64_t* relu_mask, int64_t n, void* stream);
