@@ -18,7 +18,7 @@ LIB = CSRC / "libbdetr.so"
 OBJ_DIR = CSRC / "_obj"
 SOURCES = ["common.cpp", "igemm.hip", "sgemm.hip", "p16.hip", "attention.hip", "augment.hip", "norm.hip", "elementwise.hip", "panoptic.hip", "matcher.hip", "optim.hip"]
 ARCH = "gfx950"
-COMMON_FLAGS = ["-O3", "-fPIC", f"--offload-arch={ARCH}", "-std=c++20", "-Wall", "-Wno-unused-function"]
+COMMON_FLAGS = ["-O3", "-fPIC", f"--offload-arch={ARCH}", "-std=c++20", "-Wall", "-Wno-unused-function"] + os.environ.get("BDETR_CXXFLAGS", "").split()
 # the matcher must not contract a*b+c into fma (scipy / numpy evaluate unfused); see matcher.hip
 PER_FILE_FLAGS = {"matcher.hip": ["-ffp-contract=off"]}
 

@@ -257,7 +257,9 @@ __device__ __forceinline__ void direct_epilogue(f32x16 (&acc)[BM / WM / 32][BN /
 #pragma unroll
             for (int a = 0; a < TM; ++a) {
                 float old[TN][16];
-                unsigned keep[TN][16];
+                unsigned keep[TN];
+#pragma unroll
+                for (int b = 0; b < TN; ++b) keep[b] = 0u;
                 unsigned ro = (unsigned)(a * 32) * ldc4;
                 unsigned nrow = (unsigned)(i0 + wm * WTM + 4 * lh + a * 32) * (unsigned)g.ldc + (unsigned)jl;      // element index of (e = 0, b = 0)
 #pragma unroll
@@ -268,7 +270,7 @@ __device__ __forceinline__ void direct_epilogue(f32x16 (&acc)[BM / WM / 32][BN /
                         if constexpr (MASKED) {
                             const unsigned n = nrow + 32u * b;
                             const unsigned wo = vcol[b] == FAR ? OOB : ((((n >> 8) << 2) | (n & 3u)) << 3) + ((n >> 5) & 4u);     // the dword holding bit (n >> 2) & 63
-                            keep[b][e] = (__builtin_amdgcn_raw_buffer_load_b32(rsM, wo, 0, 0) >> ((n >> 2) & 31u)) & 1u;
+                            keep[b] |= ((__builtin_amdgcn_raw_buffer_load_b32(rsM, wo, 0, 0) >> ((n >> 2) & 31u)) & 1u) << e;
                         }
                     }
                     ro += (e & 3) == 3 ? 5u * ldc4 : ldc4;
@@ -278,7 +280,7 @@ __device__ __forceinline__ void direct_epilogue(f32x16 (&acc)[BM / WM / 32][BN /
                 for (int b = 0; b < TN; ++b)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
-                        if constexpr (MASKED) acc[a][b][e] += keep[b][e] ? old[b][e] : 0.f;
+                        if constexpr (MASKED) acc[a][b][e] += ((keep[b] >> e) & 1u) ? old[b][e] : 0.f;
                         else acc[a][b][e] += old[b][e];
                     }
             }
@@ -299,13 +301,15 @@ __device__ __forceinline__ void direct_epilogue(f32x16 (&acc)[BM / WM / 32][BN /
                 const bool jok = j < g.J;
                 const float bm = jok ? g.bnb_mean[j] : 0.f, brs = jok ? g.bnb_rstd[j] : 0.f, bgm = jok ? g.bnb_gamma[j] : 0.f, bbt = jok ? g.bnb_beta[j] : 0.f;
                 float yv[TM][16];
-                unsigned keep[TM][16];
+                unsigned keep[TM];                        // bit e = the ReLU decision of accumulator register e of block (a, b)
+#pragma unroll
+                for (int a = 0; a < TM; ++a) keep[a] = 0u;
                 for_rows([&](int a, int e, unsigned ro) {
                     yv[a][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsY, vcol[b] + ro, 0, 0));
                     if constexpr (BITS) {
                         const unsigned n = (unsigned)(i0 + wm * WTM + 4 * lh + a * 32 + (e & 3) + 8 * (e >> 2)) * (unsigned)g.ldc + (unsigned)j;
                         const unsigned wo = vcol[b] == FAR ? OOB : ((((n >> 8) << 2) | (n & 3u)) << 3) + ((n >> 5) & 4u);
-                        keep[a][e] = (__builtin_amdgcn_raw_buffer_load_b32(rsB, wo, 0, 0) >> ((n >> 2) & 31u)) & 1u;
+                        keep[a] |= ((__builtin_amdgcn_raw_buffer_load_b32(rsB, wo, 0, 0) >> ((n >> 2) & 31u)) & 1u) << e;
                     }
                 });
                 float sg = 0.f, sgx = 0.f;
@@ -315,7 +319,7 @@ __device__ __forceinline__ void direct_epilogue(f32x16 (&acc)[BM / WM / 32][BN /
                     for (int e = 0; e < 16; ++e) {
                         const bool in = wm * WTM + 4 * lh + a * 32 + (e & 3) + 8 * (e >> 2) < rows_here;
                         bool on;
-                        if constexpr (BITS) on = in && keep[a][e] != 0u;
+                        if constexpr (BITS) on = in && ((keep[a] >> e) & 1u) != 0u;
                         else on = in && (!g.bnb_relu || (__builtin_fmaf(yv[a][e] - bm, brs * bgm, bbt) > 0.f));      // = norm.hip's bn_affine
                         const float ge = on ? acc[a][b][e] : 0.f;
                         sg += ge; sgx += ge * ((yv[a][e] - bm) * brs);
@@ -373,6 +377,7 @@ __device__ __forceinline__ void atomic_epilogue(f32x16 (&acc)[BM / WM / 32][BN /
                 __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, rsC, vcol[b] + ro, 0, 0);
             }
             ro += (e & 3) == 3 ? 5u * ldc4 : ldc4;
+            asm volatile("" : "+v"(ro));         // a running offset, not 32 precomputed ones (they spilled)
         }
 }
 
@@ -653,6 +658,7 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
         float bias_pre[TN];
         gemm_load_bias<BM, BN, WM, WN>(g, j0, bias_pre);              // lands during the K loop
         if (nk > 0) issue_all(0, r_begin);
+#ifdef BDETR_SGEMM_STAMPS      // diagnostic builds only (BDETR_CXXFLAGS=-DBDETR_SGEMM_STAMPS): the stamp array costs the production kernels ~90 VGPRs
         if ((g.dbg & 32) && blockIdx.x == 1 && blockIdx.z == 0 && wave == 0) {
             // diagnostic: cycle stamps of workgroup 1's first wave over its first 12 K-steps (bdetr_sgemm_debug_stamps):
             // per step {after the load wait, after the barrier, after issuing the next stage, after issuing the MFMAs}
@@ -676,6 +682,7 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
             }
             if (lane == 0) for (int i = 0; i < 48; ++i) g_stamps[i] = st[i];
         } else
+#endif
         for (int kt = 0; kt < nk; kt += 2) {
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             if (kt + 1 < nk) issue_all(1, r_begin + (kt + 1) * BK);

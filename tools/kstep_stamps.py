@@ -1,6 +1,7 @@
 """Cycle stamps of one workgroup's first 12 K-steps of a pre-split 3x3 forward launch (BDETR_SGEMM_DBG=32 is set here):
 per step the time spent waiting for the stage's loads, in the barrier, issuing the next stage, and issuing the MFMAs.
-Usage: python tools/kstep_stamps.py [H C K R]"""
+Needs a diagnostic build of the library: BDETR_CXXFLAGS=-DBDETR_SGEMM_STAMPS python -m boosted_detr_amd.build --force
+(the stamp array is compiled out of the production kernels).  Usage: python tools/kstep_stamps.py [H C K R]"""
 import ctypes as C
 import os
 import sys
