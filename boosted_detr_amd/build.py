@@ -41,7 +41,7 @@ def _digest(paths) -> str:
 def build(force: bool = False, verbose: bool = True) -> Path:
     deps = [CSRC / s for s in SOURCES] + [CSRC / "common.h", CSRC / "gemm_common.h", CSRC / "p16.h", CSRC.parent.parent / "include" / "bdetr.h"]
     stamp = CSRC / "_obj" / "stamp"
-    dig = _digest(deps)
+    dig = _digest(deps) + "|" + " ".join(COMMON_FLAGS)          # a build with other flags (BDETR_CXXFLAGS) is a different library
     if not force and LIB.exists() and stamp.exists() and stamp.read_text() == dig:
         return LIB
     OBJ_DIR.mkdir(exist_ok=True)
