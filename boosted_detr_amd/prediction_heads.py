@@ -42,7 +42,10 @@ class _Head(Layer):
             raise NotImplementedError("Conv1D re-count branch (prediction_heads.py:120-123) is off the hot path")
         x = self.DenseHidden(features, K.ACT_RELU)
         x = ops.batchnorm(x, self.BatchNorm, training and self.trainable, bessel=False)
-        return self.DenseOut(x)
+        # the pre-activation output (softmax / sigmoid / box-sigmoid input: prediction_heads.py:111,180,44) stays reachable
+        # as `last_logits`: the parity tests compare it with the oracle's, the north star's "logits within 1e-3"
+        self.last_logits = self.DenseOut(x)
+        return self.last_logits
 
     def get_config(self):
         c = super().get_config()

@@ -482,12 +482,18 @@ class Net:
             x = F.relu(self.dense(x, dname))
             return self.bn(x, bname, KERAS_BN_EPS, training, channel_dim=2)
 
+        # the pre-activation outputs (prediction_heads.py:111 softmax input, 180 sigmoid input, 44 box-sigmoid input) are kept as
+        # probes "<head>/logits": the parity tests compare them as well as the activated predictions
         c = f"CategoryPredictionHead{suffix}"
-        cat = torch.softmax(self.dense(trunk(dec, f"{c}/DenseCateg", f"{c}/BatchNorm"), f"{c}/DenseLogits"), dim=-1)
+        cat_logits = self.dense(trunk(dec, f"{c}/DenseCateg", f"{c}/BatchNorm"), f"{c}/DenseLogits")
+        cat = torch.softmax(cat_logits, dim=-1)
         a = f"AttributePredictionHead{suffix}"
-        att = torch.sigmoid(self.dense(trunk(dec, f"{a}/Dense", f"{a}/BatchNorm"), f"{a}/DenseLinear"))
+        att_logits = self.dense(trunk(dec, f"{a}/Dense", f"{a}/BatchNorm"), f"{a}/DenseLinear")
+        att = torch.sigmoid(att_logits)
         b = f"BoxPredictionHead{suffix}"
-        box = 3.0 * torch.sigmoid(self.dense(trunk(dec, f"{b}/Dense", f"{b}/BatchNorm"), f"{b}/BoxCoords") / 100.0) - 1.0
+        box_logits = self.dense(trunk(dec, f"{b}/Dense", f"{b}/BatchNorm"), f"{b}/BoxCoords")
+        box = 3.0 * torch.sigmoid(box_logits / 100.0) - 1.0
+        self.probes[f"{c}/logits"], self.probes[f"{a}/logits"], self.probes[f"{b}/logits"] = cat_logits, att_logits, box_logits
         return cat, att, box
 
 

@@ -58,10 +58,17 @@ def build(cfg, batch, tag, out):
         for pk, pv in o.probes.items():
             out[f"{tag}/{name}/probe/{pk}"] = probe_slice(pv)
             out[f"{tag}/{name}/probe_sum/{pk}"] = np.array(float(pv.detach().double().sum()))
+            if pk.endswith("/logits"):
+                # the heads' pre-activation outputs in full (the attribute head's 296 columns: every 16th, like its predictions)
+                a = pv.detach().numpy()
+                out[f"{tag}/{name}/logits/{pk[:-7]}"] = a[:, :, ::16] if a.shape[-1] > 64 else a
         for pk in GRAD_PROBES:
             if pk in g:
                 out[f"{tag}/{name}/grad_norm/{pk}"] = np.array(np.linalg.norm(g[pk].astype(np.float64)))
                 out[f"{tag}/{name}/grad_slice/{pk}"] = probe_slice(torch.from_numpy(np.ascontiguousarray(g[pk])))
+                if g[pk].size <= 16384:
+                    # whole gradient tensors (small ones): the GPU test bounds the relative L2 error against these, not a norm
+                    out[f"{tag}/{name}/grad_full/{pk}"] = g[pk].astype(np.float32)
 
 
 def main():
