@@ -65,23 +65,38 @@ def make_batch(B, H, W, M, C, seed, A=3):
 
 def is_config2(args) -> bool:
     return (args.model == "detr" and not args.fashionpedia and args.backbone == "ResNet" and args.image == 640
-            and not args.image_w and args.layers == 6 and args.queries == 100)
+            and not args.image_w and args.layers == 6 and args.queries == 100 and not args.panoptic)
+
+
+def is_config5(args) -> bool:
+    """BASELINE.json configs[4]: 1333x800 inputs, ResNet-101, 6+6, 300 queries (+ the panoptic mask head with --panoptic)."""
+    return (args.model == "detr" and not args.fashionpedia and args.backbone == "ResNet101" and args.image == 800 and args.image_w == 1333
+            and args.layers == 6 and args.queries == 300)
+
+
+GFLOP_PER_IMAGE_CONFIG5 = 1027.0       # SURVEY.md 8(d): forward 171.46 GMAC => ~1,027 GFLOP per image for the training step
+GFLOP_PANOPTIC_FWD = 23.0              # the mask head's forward: ~11.5 GMAC per image (DESIGN.md)
 
 
 def workload_name(args) -> str:
     w = args.image_w or args.image
     if is_config2(args):
-        tag = "configs[1]"
+        tag = "configs[3] per-GPU share (global 256 on 8 GPUs = 32 per GPU)" if args.batch == 32 else "configs[1]"
     elif args.model == "boosted":
-        tag = "configs[2] variant"
+        tag = "configs[2]" if (args.fashionpedia and args.learners == 3 and args.image == 640 and not args.image_w and args.queries == 100
+                               and args.backbone == "ResNet") else "configs[2] variant"
+    elif is_config5(args):
+        tag = "configs[4] (no reference counterpart)" if args.panoptic else "configs[4] detection path only (no reference counterpart)"
     elif args.backbone == "ResNet101":
         tag = "configs[4] variant (no reference counterpart)"
     else:
         tag = "custom"
     arch = (f"BoostedDETR {args.learners} weak learners" if args.model == "boosted" else f"DETR {args.layers} enc + {args.layers} dec")
     heads = "Fashionpedia 46 categories / 294 attributes" if args.fashionpedia else "COCO-80"
-    return (f"{tag}: {arch}, {args.backbone}-50 backbone {args.image}x{w}, d=256 h=8, {args.queries} queries, {heads}, dropout 0.1, "
-            f"SGD-Nesterov clipnorm step").replace("ResNet101-50", "ResNet-101").replace("ResNet-50 backbone", "ResNet-50 backbone")
+    bb = "ResNet-101" if args.backbone == "ResNet101" else "ResNet-50"
+    pan = " + panoptic mask head forward (PanopticAttention + PanopticNeck, 300 masks of 23x23)" if args.panoptic else ""
+    return (f"{tag}: {arch}, {bb} backbone {args.image}x{w}, d=256 h=8, {args.queries} queries, {heads}, dropout 0.1, "
+            f"SGD-Nesterov clipnorm step{pan}")
 
 
 def build_model(args):
@@ -94,23 +109,44 @@ def build_model(args):
     model = cls(num_object_preds=args.queries, image_size=(args.image, args.image_w or args.image), num_encoder_blocks=args.layers,
                 num_encoder_heads=8, encoder_dim=256, num_decoder_blocks=args.learners if args.model == "boosted" else args.layers,
                 num_decoder_heads=8, decoder_dim=256, num_panoptic_heads=1, panoptic_dim=32, vocab_dict=vocab,
-                attribute_weight=1.0 if args.fashionpedia else 0.0, backbone_name=args.backbone)
+                attribute_weight=1.0 if args.fashionpedia else 0.0, backbone_name=args.backbone,
+                **({"with_panoptic_head": True} if getattr(args, "panoptic", False) else {}))
     # notebook cell 26: SGD(CosineDecayRestarts(1e-3, 4000, m_mul=.95, alpha=.1), momentum=.9, nesterov=True, clipnorm=.1)
     model.compile(optimizer=SGD(CosineDecayRestarts(1e-3, 4000, m_mul=0.95, alpha=0.1), momentum=0.9, nesterov=True, clipnorm=0.1))
     return model
 
 
 def hbm_traffic_per_launch():
-    """HBM bytes per igemm launch from the PMC passes committed under profiles/ (rocprofv3 --pmc
-    FETCH_SIZE and --pmc WRITE_SIZE in separate runs of this same command, with the gfx950 corrections
-    of MI355X_MICROARCH.md: FETCH_SIZE x2, KB units).  None when the file is absent."""
-    for name in ("r02_gemm_hbm_traffic.json", "r01_igemm_hbm_traffic.json"):
+    """HBM bytes per conv/GEMM launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and --pmc
+    WRITE_SIZE in separate runs of this same command, with the gfx950 corrections of MI355X_MICROARCH.md: FETCH_SIZE x2, KB
+    units), newest round first, and where the figure comes from (counters cannot be collected inside a timed run: the
+    provenance names the file and the commit of the profiled build).  (None, None) when no file is present."""
+    for name in ("r03_gemm_hbm_traffic.json", "r02_gemm_hbm_traffic.json", "r01_igemm_hbm_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
-                return round(json.load(f)["hbm_bytes_per_launch"])
+                d = json.load(f)
+            return round(d["hbm_bytes_per_launch"]), {"file": f"profiles/{name}", "profiled_commit": d.get("commit"), "steps": d.get("steps")}
         except Exception:
             continue
-    return None
+    return None, None
+
+
+# Environment switches of the library / host runtime.  A benchmark line is only comparable when none of them changes what the
+# step does: the diagnostic ones (work compiled out of a launch) make bench.py refuse to run, every other one that is set is
+# recorded in config.env_overrides.
+ENV_REFUSED = ("BDETR_SGEMM_DBG",)
+ENV_RECORDED = ("BDETR_STILE", "BDETR_TILE", "BDETR_P16", "BDETR_BN_FUSE", "BDETR_LAZY_SKIP", "BDETR_WGRAD_WANT", "BDETR_WGRAD_MINSTAGES",
+                "BDETR_GEMM_PRECISION", "BDETR_SIDE_STREAM", "BDETR_SIDE_PRIORITY", "BDETR_GRAPH", "BDETR_DP_OVERLAP", "BDETR_DP_FORCE", "BDETR_LIB",
+                "BDETR_CXXFLAGS", "BDETR_FORCE_DEVICE", "BDETR_DIST_BACKEND", "BDETR_CPU_THREADS", "BDETR_XFUSE", "BDETR_TFAST")
+
+
+def env_overrides() -> dict:
+    bad = [k for k in ENV_REFUSED if os.environ.get(k) not in (None, "", "0")]
+    if bad:
+        raise SystemExit(f"bench.py refuses to run with diagnostic switches set ({', '.join(bad)}): they compile work out of the kernels")
+    known = set(ENV_REFUSED) | set(ENV_RECORDED)
+    stray = sorted(k for k in os.environ if k.startswith("BDETR_") and k not in known and k != "BDETR_PROF_DUMP")
+    return {k: os.environ[k] for k in list(ENV_RECORDED) + stray if k in os.environ}
 
 
 PEAK_HBM_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E 8 TB/s (6.3 TB/s measured for a float4 copy)
@@ -216,22 +252,24 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (config 2: 16)")
+    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (configs[1]: 16; configs[3]: 32 = global 256 on 8 GPUs)")
     ap.add_argument("--image", type=int, default=640)
     ap.add_argument("--layers", type=int, default=6)
     ap.add_argument("--queries", type=int, default=100)
-    ap.add_argument("--image-w", type=int, default=0, help="image width when not square (config 5: --image 800 --image-w 1333)")
+    ap.add_argument("--image-w", type=int, default=0, help="image width when not square (configs[4]: --image 800 --image-w 1333)")
     ap.add_argument("--model", choices=["detr", "boosted"], default="detr", help="configs[2]: --model boosted --learners 3 --fashionpedia")
     ap.add_argument("--learners", type=int, default=3)
     ap.add_argument("--fashionpedia", action="store_true", help="46 categories / 294 attributes, attribute_weight 1.0")
     ap.add_argument("--backbone", default="ResNet", choices=["ResNet", "ResNet101"], help="configs[4]: ResNet101 (no reference counterpart)")
+    ap.add_argument("--panoptic", action="store_true", help="configs[4]: append the panoptic mask head's forward (PanopticAttention + PanopticNeck on the "
+                    "step's encoder output) to every step: --backbone ResNet101 --image 800 --image-w 1333 --queries 300 --batch 8 --panoptic")
     ap.add_argument("--no-fp32-policy", action="store_true", help="skip the secondary measurement under the exact-fp32 arithmetic policy")
     ap.add_argument("--no-batch32", action="store_true", help="skip the secondary measurement at configs[3]'s per-GPU batch (32)")
-    ap.add_argument("--graph", action="store_true", help="replay the step as a captured hipGraph (Model.use_graph) instead of enqueuing it from "
-                    "Python: host-free steps, but measured slower than eager + side stream on ROCm 7.2 (profiles/README.md)")
+    ap.add_argument("--graph", action="store_true", help="replay the step as captured hipGraph segments (Model.use_graph) instead of enqueuing it from Python")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
+    overrides = env_overrides()               # refuses diagnostic switches; everything else that is set goes into the line
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -239,21 +277,34 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
-    # BDETR_FORCE_DEVICE / BDETR_DIST_BACKEND exist only to rehearse the N>1 code path on a one-GPU box
-    # (two ranks sharing cuda:0 over gloo); the driver's runs use one GPU per rank over RCCL ("nccl").
+    # BDETR_FORCE_DEVICE / BDETR_DIST_BACKEND / BDETR_DP_FORCE exist only to rehearse the N>1 code path on a one-GPU box (two
+    # ranks sharing cuda:0 over gloo, or ONE rank over a real RCCL communicator); the driver's runs use one GPU per rank over
+    # RCCL ("nccl").  All three are recorded in config.env_overrides when set.
     dev_index = int(os.environ.get("BDETR_FORCE_DEVICE", local_rank))
     torch.cuda.set_device(dev_index)
     dist = None
-    if world > 1:
+    dist_info = None
+    distributed = world > 1 or os.environ.get("BDETR_DP_FORCE", "0") == "1"
+    if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
         backend = os.environ.get("BDETR_DIST_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        # what the collective library itself reports, so that "RCCL saw N ranks" can be checked from the line
+        ver = None
+        try:
+            ver = ".".join(str(x) for x in torch.cuda.nccl.version()) if backend == "nccl" else None
+        except Exception:
+            pass
+        dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rccl_version": ver,
+                     "device_per_rank": "one GPU per rank" if "BDETR_FORCE_DEVICE" not in os.environ else f"all ranks on cuda:{dev_index} (rehearsal)"}
 
     from boosted_detr_amd import _lib
+    from boosted_detr_amd import kernels as K
     from boosted_detr_amd.engine import to_device
     L = _lib.lib()
 
@@ -267,20 +318,31 @@ def main():
              "attribute": to_device(host["attribute"], torch.int32),
              "bbox": to_device(host["bbox"]), "num_objects": to_device(host["num_objects"], torch.int32)}
 
-    if world > 1:
+    if distributed:
         model.distribute()
-    model.use_graph = args.graph and world == 1             # N > 1: the collectives are issued per bucket from the backward pass (eager)
+    model.use_graph = args.graph and not distributed       # N > 1: the collectives are issued per bucket from the backward pass (eager)
+
     def note(msg):
         if rank == 0:
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
+    masks = [None]
+
+    def run_step(b):
+        """One step of the workload: the unmodified train_step (+ the mask head's forward on that step's features with --panoptic)."""
+        model.train_step(b)
+        if args.panoptic:
+            masks[0] = model.panoptic_masks()
+
     for i in range(max(args.warmup, 1)):
         tw = time.perf_counter()
-        model.train_step(batch)
+        run_step(batch)
         torch.cuda.synchronize()
         note(f"warm-up step {i}: {(time.perf_counter() - tw) * 1e3:.1f} ms")
-    if world > 1:
+    if distributed:
         model._dp.broadcast_variables(model.variables)
+    model.guard_flush()
+    redos_before = model.range_redos
 
     def barrier():
         if dist is not None:
@@ -291,9 +353,37 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        model.train_step(batch)
+        run_step(batch)
     barrier()
     elapsed = time.perf_counter() - t0
+    # The range guard of the timed region: resolve the flag snapshots still in flight (outside the timed region) and report.  A
+    # raised guard means steps inside the region applied no update and were redone: the line says so instead of hiding it.
+    model.guard_flush()
+    torch.cuda.synchronize()
+    guard = {"range_redos_in_timed_region": model.range_redos - redos_before, "update_free_attempts": model.range_skipped,
+             "overflow_flag_after_run": int(K.overflow_flag().item()), "policy_guarded": bool(model._guarded()),
+             "check": "async flag snapshot after every step, examined 2 steps later (Model._guard_poll)"}
+
+    # Data-parallel legs (N > 1): a few more steps with events on the communication stream around every bucket's all-reduce.
+    allreduce = None
+    if distributed:
+        model._dp.profile = True
+        for _ in range(min(5, args.steps)):
+            run_step(batch)
+        allreduce = model._dp.profile_summary()
+        model._dp.profile = False
+
+    # the mask head alone (events on the launch stream), next to the step it is appended to
+    panoptic = None
+    if args.panoptic:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            masks[0] = model.panoptic_masks()
+        e1.record()
+        torch.cuda.synchronize()
+        panoptic = {"head_forward_ms": round(e0.elapsed_time(e1) / 5, 3), "masks_shape": list(masks[0].shape), "finite": bool(torch.isfinite(masks[0]).all()),
+                    "gflop_forward_per_image": GFLOP_PANOPTIC_FWD, "arithmetic": "exact fp32 MFMA (library default policy outside the training step)"}
 
     # Roofline leg: the SAME K steps again, right after the timed region, with every launch of the
     # dominant (igemm / MFMA) kernel family bracketed by hipEvents on its launch stream.  Bracketing
@@ -310,7 +400,7 @@ def main():
         L.bdetr_prof_enable(1 if rank == 0 else 0)
         t1 = time.perf_counter()
         for _ in range(args.steps):
-            model.train_step(batch)
+            run_step(batch)
         torch.cuda.synchronize()
         prof_wall = time.perf_counter() - t1
         _engine.set_side_stream_enabled(side_was)
@@ -337,8 +427,10 @@ def main():
             # the family mixes arithmetics: its peak is the FLOP-weighted harmonic mean of their peaks, i.e.
             # (algorithmic FLOPs) / (time the same launches would take at each one's MFMA peak)
             peak = fl.value / (peak_ms * 1e-3) / 1e12
+            traffic, traffic_src = hbm_traffic_per_launch()
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": hbm_traffic_per_launch(),
+                    "frac": round(ach / peak, 4), "traffic": traffic if is_config2(args) else None,
+                    "traffic_provenance": traffic_src if is_config2(args) else None,
                     "kernel": "igemm_kernel + sgemm_kernel (MFMA implicit-GEMM family: conv fwd/bwd-data/bwd-weight, dense; algorithmic FLOPs = 2*I*J*R)",
                     "peak_note": "FLOP-weighted harmonic mean of the per-arithmetic peaks in by_arithmetic (fp32 MFMA 157.3; split = 2500/3)",
                     "by_arithmetic": by_arith,
@@ -354,7 +446,7 @@ def main():
                                 f"the chip ({prof_wall / args.steps * 1e3:.2f} ms/step in that mode)"}
     # Secondary measurement at BASELINE.json configs[3]'s per-GPU batch (global 256 on 8 GPUs = 32 per GPU): the same
     # model and step, a batch of 32 resident images per rank.  `value` above stays the fixed 16-per-GPU weak-scaling
-    # series; this one is reported next to it in config.configs3.
+    # series; this one is reported next to it in config.configs3 (and is a first-class line of its own with --batch 32).
     b32 = None
     if not args.no_batch32 and is_config2(args) and args.batch != 32:
         host32 = make_batch(32, args.image, args.image, 100, 82, seed=4321 + rank)
@@ -377,6 +469,7 @@ def main():
         b32 = {"per_gpu_batch": 32, "global_batch": 32 * world, "steps": k32, "ms_per_step": round(e32 / k32 * 1e3, 3),
                "value": round(32 * world * k32 / e32, 2), "unit": "images/s"}
         del batch32
+        model.guard_flush()
     # The same step under the exact-fp32 policy (every conv/GEMM product on v_mfma_f32_32x32x2_f32, the reference's
     # arithmetic): reported next to the headline so that the reference-precision throughput is driver-timed too.
     fp32_line = None
@@ -398,7 +491,7 @@ def main():
             ef = float(t.item())
         fp32_line = {"value": round(args.batch * world * kf / ef, 2), "unit": "images/s", "steps": kf, "ms_per_step": round(ef / kf * 1e3, 3),
                      "arithmetic": "every conv/GEMM product exact fp32 (v_mfma_f32_32x32x2_f32)"}
-    if world > 1:
+    if distributed:
         barrier()
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -411,19 +504,26 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = global_batch * args.steps / elapsed
         logs = model.logs_to_host(model.step_logs())
+        gflop_img = GFLOP_PER_IMAGE if is_config2(args) else (GFLOP_PER_IMAGE_CONFIG5 + (GFLOP_PANOPTIC_FWD if args.panoptic else 0.0)) if is_config5(args) else None
         out = {
-            "metric": METRIC, "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": METRIC if not is_config5(args) else "images/sec training step (fwd+matcher+loss+bwd" + (" + mask head fwd" if args.panoptic else "") + "), 1333x800 N=300",
+            "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": dtype_note(model), "arithmetic": arithmetic_note(model), "data": "synthetic",
             "config": {"workload": workload_name(args), "per_gpu_batch": args.batch, "global_batch": global_batch,
-                       "parallelism": f"dp{world}", "step_launch": "hipGraph replay" if model.use_graph else "eager", "gflop_per_image_algorithmic": GFLOP_PER_IMAGE if is_config2(args) else None,
-                       "configs3": b32},
-            "tflops_algorithmic": round(value * GFLOP_PER_IMAGE / 1e3, 2) if is_config2(args) else None,
+                       "parallelism": f"dp{world}", "step_launch": "hipGraph replay" if model.use_graph else "eager", "gflop_per_image_algorithmic": gflop_img,
+                       "configs3": b32, "env_overrides": overrides, "distributed": dist_info},
+            "tflops_algorithmic": round(value * gflop_img / 1e3, 2) if gflop_img else None,
             "final_loss": round(logs.get("loss", float("nan")), 4),
+            "range_guard": guard,
+            "allreduce": allreduce,
+            "panoptic": panoptic,
             "value_fp32_policy": fp32_line,
             "roofline": roof,
-            "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(args),
+            "cpu_baseline": None if (args.no_cpu_baseline or world > 1 or not is_config2(args)) else cpu_baseline(args),
         }
+        if guard["overflow_flag_after_run"] != 0:
+            raise SystemExit(f"bench.py: the range guard is still raised after the run ({guard}): the timed steps are not valid")
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -39,8 +39,18 @@ struct GemmParams {
     // ReLU mask of the element (norm.hip relu_mask_bits4 layout) - the skip branch of a residual unit merged without ever
     // materialising its masked gradient
     const unsigned long long* acc_mask;
-    int dbg;                            // diagnostic builds of a launch (sgemm.hip, BDETR_SGEMM_DBG; tools/epi_probe.py): 1 = no C stores, 2 = no K loop, 4 = per-element stores; 0 in production
+#ifdef BDETR_SGEMM_DIAG
+    int dbg;                            // diagnostic builds only (tools/epi_probe.py): BDETR_SGEMM_DBG bits 1 = no C stores, 2 = no K loop, 4 = per-element stores, 8 = no fragment reads / MFMAs, 16 = no staging loads
+#endif
 };
+
+// Diagnostic switches that compile work OUT of a launch exist only in builds made with BDETR_CXXFLAGS=-DBDETR_SGEMM_DIAG
+// (tools/epi_probe.py); in the production library the test is the constant false and the environment variable is never read.
+#ifdef BDETR_SGEMM_DIAG
+#define BDETR_DBG(g, bits) (((g).dbg & (bits)) != 0)
+#else
+#define BDETR_DBG(g, bits) false
+#endif
 
 inline void init_params(GemmParams& g) {
     g = GemmParams{};
@@ -188,7 +198,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
                 if constexpr (ACCUM) val[it] += old[it];
-                if ((g.dbg & 1) && val[it][0] != 1234567.f) continue;
+                if (BDETR_DBG(g, 1) && val[it][0] != 1234567.f) continue;
                 if (ok[it]) *reinterpret_cast<f32x4*>(dst[it]) = val[it];
             }
             if constexpr (BNB) {

@@ -499,7 +499,7 @@ namespace {
 // bdetr_set_gemm_precision() changes it at run time.  use_split(grad) answers for one product.
 }  // namespace
 namespace bdgemm {
-int g_gemm_mode = -1;
+thread_local int g_gemm_mode = -1;     // per host thread (include/bdetr.h): the one mode word the library keeps
 int gemm_mode() {
     if (g_gemm_mode < 0) {
         const char* e = getenv("BDETR_GEMM_PRECISION");

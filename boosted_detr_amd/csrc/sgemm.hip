@@ -176,7 +176,9 @@ struct XXPatch {
 // ----------------------------------------------------------------------------------------
 __device__ __forceinline__ int xx_swz(int r) { return ((r & 1) << 3) | ((r >> 1) & 1); }
 
+#if defined(BDETR_SGEMM_STAMPS) && defined(BDETR_SGEMM_DIAG)
 __device__ unsigned long long g_stamps[64];      // diagnostic cycle stamps (BDETR_SGEMM_DBG bit 32)
+#endif
 
 constexpr int lds_bytes_for(int bm, int bn, int ns) { return ns * (bm + bn) * 128 > bm * bn * 4 ? ns * (bm + bn) * 128 : bm * bn * 4; }
 
@@ -238,7 +240,7 @@ __device__ __forceinline__ void direct_epilogue(f32x16 (&acc)[BM / WM / 32][BN /
                     const unsigned vo = (ro != OOB && jl + b * 32 < g.J) ? ro + (unsigned)(jl + b * 32) * 4u : OOB;
                     float v = acc[a][b][e];
                     if (accum) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsC, vo, 0, 0));
-                    if (!(g.dbg & 1)) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsC, vo, 0, 0);
+                    if (!BDETR_DBG(g, 1)) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsC, vo, 0, 0);
                 }
             }
         return;
@@ -335,7 +337,7 @@ __device__ __forceinline__ void direct_epilogue(f32x16 (&acc)[BM / WM / 32][BN /
         };
         if (g.bnb_mask != nullptr) bn_sums(std::true_type{}); else bn_sums(std::false_type{});
     }
-    if (g.dbg & 1) return;
+    if (BDETR_DBG(g, 1)) return;
     for_rows([&](int a, int e, unsigned ro) {
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
@@ -500,7 +502,7 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
     };
     constexpr int NLOAD = NIA + NIB;
     auto issue_all = [&](int buf, int r0) {
-        if (g.dbg & 16) return;                          // diagnostic: no staging loads
+        if (BDETR_DBG(g, 16)) return;                    // diagnostic builds: no staging loads
         [&]<int... L>(std::integer_sequence<int, L...>) { (issue_one(buf, r0, std::integral_constant<int, L>{}), ...); }(std::make_integer_sequence<int, NLOAD>{});
         if constexpr (!XX) { LA::step_next(opa, stA); LB::step_next(opb, stB); }
         else {
@@ -574,7 +576,7 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
     // issue cost (address VALU + M0 + buffer_load ... lds) then hides in the shadow of the preceding MFMAs instead of
     // running as a serial preamble in front of them.
     auto kstep = [&](int buf) {
-        if (g.dbg & 8) return;                           // diagnostic: no fragment reads / MFMAs
+        if (BDETR_DBG(g, 8)) return;                     // diagnostic builds: no fragment reads / MFMAs
         const unsigned char* tA = lds + buf * STAGE_BYTES;
         const unsigned char* tB = tA + A_BYTES;
 #pragma unroll
@@ -620,7 +622,7 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
         // the NEXT tile's first two stages are issued into the (idle) ring BEFORE this tile's epilogue: the C stores
         // and the next tile's first HBM round trip overlap instead of following each other (measured on the 64 -> 256
         // channel 1x1 layer at 160x160: loads + MFMAs alone 76 us, stores alone 89 us, one after the other 141 us).
-        const int nk = (g.dbg & 2) ? 0 : (g.R + BK - 1) / BK;
+        const int nk = BDETR_DBG(g, 2) ? 0 : (g.R + BK - 1) / BK;
         auto prefetch = [&]() { if (nk > 0) issue_all(0, 0); if (nk > 1) issue_all(1, BK); };
         prefetch();
         for (;;) {
@@ -654,12 +656,12 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
         // One barrier per K-step: wait for my share of stage kt, barrier (every wave's share has landed and every wave
         // is done reading stage kt - 1), refill that buffer with stage kt + 1, compute.  (Loads issued early - before the
         // MFMAs, not between them - measured faster: they have the whole K-step to land.)
-        const int nk = (g.dbg & 2) ? 0 : (r_end - r_begin + BK - 1) / BK;
+        const int nk = BDETR_DBG(g, 2) ? 0 : (r_end - r_begin + BK - 1) / BK;
         float bias_pre[TN];
         gemm_load_bias<BM, BN, WM, WN>(g, j0, bias_pre);              // lands during the K loop
         if (nk > 0) issue_all(0, r_begin);
-#ifdef BDETR_SGEMM_STAMPS      // diagnostic builds only (BDETR_CXXFLAGS=-DBDETR_SGEMM_STAMPS): the stamp array costs the production kernels ~90 VGPRs
-        if ((g.dbg & 32) && blockIdx.x == 1 && blockIdx.z == 0 && wave == 0) {
+#if defined(BDETR_SGEMM_STAMPS) && defined(BDETR_SGEMM_DIAG)      // diagnostic builds only (BDETR_CXXFLAGS="-DBDETR_SGEMM_DIAG -DBDETR_SGEMM_STAMPS"): the stamp array costs the kernels ~90 VGPRs
+        if (BDETR_DBG(g, 32) && blockIdx.x == 1 && blockIdx.z == 0 && wave == 0) {
             // diagnostic: cycle stamps of workgroup 1's first wave over its first 12 K-steps (bdetr_sgemm_debug_stamps):
             // per step {after the load wait, after the barrier, after issuing the next stage, after issuing the MFMAs}
             unsigned long long st[48];
@@ -751,10 +753,12 @@ int launch_cfg(const typename LA::Op& a, const typename LB::Op& b, GemmParams g,
     g.tiles_j = (int)cdiv64(g.J, BN);
     dim3 grid(g.tiles_i * g.tiles_j, 1, zdim);
     g.vec_store = (g.J % 4 == 0) && (g.ldc % 4 == 0) && aligned16(g.c);
+#ifdef BDETR_SGEMM_DIAG
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("BDETR_SGEMM_DBG"); dbg = e ? atoi(e) : 0; }
     g.dbg = dbg;
     if (dbg & 4) g.vec_store = 0;
+#endif
     const bool prof = g_prof_on;
     if (prof) prof_begin(st, 2.0 * (double)g.I * (double)g.J * (double)g.R, g.I, g.J, g.R, zdim, BM, BN * 10 + NS,
                          (F16 ? AR_P16_F16 : AR_P16_BF16) * 10000 + kind);
@@ -820,13 +824,15 @@ bool is_1x1_dense(const bdetr_conv_desc* d) { return d->R == 1 && d->S == 1 && d
 // ----------------------------------------------------------------------------------------
 // C ABI
 // ----------------------------------------------------------------------------------------
-// diagnostic: the cycle stamps a launch made with BDETR_SGEMM_DBG bit 32 left behind (tools/kstep_stamps.py)
+#if defined(BDETR_SGEMM_STAMPS) && defined(BDETR_SGEMM_DIAG)
+// diagnostic builds only: the cycle stamps a launch made with BDETR_SGEMM_DBG bit 32 left behind (tools/kstep_stamps.py)
 extern "C" int bdetr_sgemm_debug_stamps(uint64_t* out, int n) {
     BDETR_CHECK_ARG(out && n > 0 && n <= 64, "bdetr_sgemm_debug_stamps: 1 <= n <= 64");
     hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(uint64_t) * (size_t)n);
     if (e != hipSuccess) { bdetr_set_error("bdetr_sgemm_debug_stamps: %s", hipGetErrorString(e)); return (int)e; }
     return 0;
 }
+#endif
 
 extern "C" int bdetr_p16_supported(const bdetr_conv_desc* d) {
     if (!d || d->C % 8 || d->K % 8) return 0;

@@ -50,6 +50,16 @@ def bump_weights_version() -> None:
     WEIGHTS_VERSION[0] += 1
 
 
+# Bumped whenever the layer tree, a variable list or a trainable flag changes: Layer.variables / trainable_variables are
+# cached per layer against it (the training step asks for them several times; walking ~400 variables with duplicate checks
+# costs milliseconds of host time per call).
+STRUCT_VERSION = [0]
+
+
+def bump_struct_version() -> None:
+    STRUCT_VERSION[0] += 1
+
+
 class Variable:
     """A model weight.  ``value`` is held in the kernels' layout (conv OHWI, dense [out][in]);
     ``numpy()`` / ``assign()`` speak the Keras layout (HWIO, [in][out])."""
@@ -59,13 +69,22 @@ class Variable:
         self.name = name
         self.keras_shape = tuple(int(s) for s in keras_shape)
         self.kind = kind
-        self.trainable = trainable
+        self._trainable = bool(trainable)
         self.pad_in_channels = pad_in_channels      # conv1: 3 -> 4 input channels (zero weights)
         self.value: Optional[torch.Tensor] = None
         self.grad: Optional[torch.Tensor] = None
         self.grad_buf: Optional[torch.Tensor] = None   # persistent slice of the optimizer's flat gradient buffer
         self._grad_flat: Optional[torch.Tensor] = None  # ... and the flat buffer it is a slice of (ops.GradSink checks it is live)
         self._grad_fresh = False                        # grad_buf already holds this step's gradient
+
+    @property
+    def trainable(self) -> bool:
+        return self._trainable
+
+    @trainable.setter
+    def trainable(self, v: bool) -> None:
+        self._trainable = bool(v)
+        bump_struct_version()          # cached trainable_variables lists are stale
 
     # layout conversion -----------------------------------------------------------------
     def _to_internal(self, a: np.ndarray) -> np.ndarray:
@@ -211,6 +230,10 @@ class Tape:
                     if acc is not None and acc[i] is not None and g is acc[i]:
                         continue                                    # the op already accumulated into the offered tensor
                     g, have = materialise(g), materialise(have)
+                    # partial sums that rode in with `have` (a BatchNorm-backward reduction fused into the epilogue that
+                    # produced it: ops.conv_bn) describe the tensor BEFORE this contribution: drop them
+                    if hasattr(have, "_bnb_parts"):
+                        del have._bnb_parts
                     if getattr(have, "_bdetr_owned", False):       # sole owner: accumulate in place
                         K.axpy_(1.0, g.view(have.shape), have)
                     else:
@@ -334,14 +357,17 @@ class Layer:
     def __setattr__(self, key, value):
         if isinstance(value, Layer) and key not in ("_parent",):
             self.__dict__.setdefault("_sublayers", []).append(value)
+            bump_struct_version()
         elif isinstance(value, list) and value and all(isinstance(v, Layer) for v in value):
             self.__dict__.setdefault("_sublayers", []).extend(value)
+            bump_struct_version()
         object.__setattr__(self, key, value)
 
     def track(self, layer: "Layer") -> "Layer":
         """Register a sub-layer appended to a list attribute after the attribute was assigned."""
         if layer not in self._sublayers:
             self._sublayers.append(layer)
+            bump_struct_version()
         return layer
 
     @property
@@ -351,6 +377,7 @@ class Layer:
     @trainable.setter
     def trainable(self, v: bool) -> None:
         self._trainable = bool(v)
+        bump_struct_version()
         for l in self._sublayers:
             l.trainable = v
 
@@ -360,6 +387,7 @@ class Layer:
         v.assign(value if value is not None else initializer(initializer_name)(v.name, tuple(shape), self._init_seed))
         v.owner = self
         self._variables.append(v)
+        bump_struct_version()
         return v
 
     scope_prefix = ""
@@ -377,16 +405,28 @@ class Layer:
 
     @property
     def variables(self) -> List[Variable]:
-        out = list(self._variables)
+        c = self.__dict__.get("_vars_cache")
+        if c is not None and c[0] == STRUCT_VERSION[0]:
+            return list(c[1])
+        out, seen = [], set()
+        for v in self._variables:
+            if id(v) not in seen:
+                seen.add(id(v)); out.append(v)
         for l in self.layers():
             for v in l.variables:
-                if v not in out:
-                    out.append(v)
-        return out
+                if id(v) not in seen:
+                    seen.add(id(v)); out.append(v)
+        object.__setattr__(self, "_vars_cache", (STRUCT_VERSION[0], out))
+        return list(out)
 
     @property
     def trainable_variables(self) -> List[Variable]:
-        return [v for v in self.variables if v.trainable and getattr(v, "owner", self).trainable]
+        c = self.__dict__.get("_tvars_cache")
+        if c is not None and c[0] == STRUCT_VERSION[0]:
+            return list(c[1])
+        out = [v for v in self.variables if v.trainable and getattr(v, "owner", self).trainable]
+        object.__setattr__(self, "_tvars_cache", (STRUCT_VERSION[0], out))
+        return list(out)
 
     def count_params(self) -> int:
         return sum(v.num_params for v in self.variables)

@@ -230,6 +230,16 @@ def overflow_flag() -> torch.Tensor:
     return _OVERFLOW[0]
 
 
+_GUARD_ACTIVE = [True]
+
+
+def set_guard_active(on: bool) -> None:
+    """Whether the running step reads and clears the overflow flag (Model: policy 'split').  Only then do BatchNorm
+    statistics watch it: under another policy nobody clears it, and a flag left up by an earlier guarded step (or by a stray
+    p16_pack of a tool) would stop the moving-statistics updates for the rest of the process."""
+    _GUARD_ACTIVE[0] = bool(on)
+
+
 def flag_nonfinite(x: torch.Tensor) -> None:
     """Set the step's range guard when x holds a non-finite value (the loss vectors: a NaN born in a kernel without
     its own range check, e.g. the in-kernel split-fp16 products of the transformer layers)."""
@@ -533,7 +543,7 @@ def bn_stats(rows, Cc, parts, eps, momentum, bessel, moving_mean, moving_var, li
     fold = L.bdetr_bn_stats_fold_rows()
     ws = empty(2 * fold * Cc, like=like) if n > 4 * fold else None
     check(L.bdetr_bn_stats(None, rows, Cc, _p(psum), _p(psq), n, eps, momentum, int(bessel), _p(mean), _p(rstd),
-                           _p(moving_mean), _p(moving_var), _p(ws), _p(overflow_flag()) if like.is_cuda else None, _stream()), "bn_stats")
+                           _p(moving_mean), _p(moving_var), _p(ws), _p(overflow_flag()) if _GUARD_ACTIVE[0] else None, _stream()), "bn_stats")
     return mean, rstd
 
 

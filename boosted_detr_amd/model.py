@@ -35,6 +35,7 @@ class DETR(Model):
                  classification_only=False, attribute_weight=1.0, name="DETR", **kwargs):
         seed = int(kwargs.pop("seed", 0))
         backbone_name = kwargs.pop("backbone_name", "ResNet")      # reference default is EfficientNet (out of scope)
+        with_panoptic_head = bool(kwargs.pop("with_panoptic_head", False))
         super().__init__(name=name, seed=seed)                      # pad_value / oov_value etc. are swallowed like the reference's **kwargs
         category_weight = box_weight = exist_weight = None
         if classification_only:
@@ -70,6 +71,27 @@ class DETR(Model):
                                                                     name="BoxPredictionHead", seed=seed)
         self.loss_fn = losses_and_metrics.MatchingLoss(category_weight=category_weight, box_weight=box_weight,
                                                        attribute_weight=attribute_weight, exist_weight=exist_weight, name="MatchingLoss")
+        # BASELINE.json configs[4]'s mask head.  The reference constructs neither layer (model.py:4 has the import commented out;
+        # num_panoptic_heads / panoptic_dim are accepted and unused), so the head is opt-in, forward-only and frozen: it runs on the
+        # features the last call left behind (`panoptic_masks`), outside the training step's tape and arithmetic policy.
+        self.PanopticAttention = self.PanopticNeck = None
+        if with_panoptic_head:
+            from . import panoptic_neck
+            self.PanopticAttention = transformers.PanopticAttention(num_attention_heads=num_panoptic_heads, hidden_dim=panoptic_dim, seed=seed)
+            self.PanopticNeck = panoptic_neck.PanopticNeck(seed=seed)
+            self.PanopticAttention.trainable = False
+            self.PanopticNeck.trainable = False
+        self._panoptic_inputs = None
+
+    def panoptic_masks(self):
+        """[B, num_object_preds, 23 * 23] mask logits of the last call's images (transformers.py:460-559 on the image encoding +
+        panoptic_neck.py:8-88), or None before the first call."""
+        if self.PanopticAttention is None:
+            raise RuntimeError("construct the model with with_panoptic_head=True")
+        if self._panoptic_inputs is None:
+            return None
+        enc, dec, pos = self._panoptic_inputs
+        return self.PanopticNeck([self.PanopticAttention([enc, dec, pos])])
 
     def get_config(self):
         c = Model.get_config(self)            # explicit base: BoostedDETR reuses this function
@@ -86,6 +108,7 @@ class DETR(Model):
         encoder_features = self.EncoderBackbone([image], training=training)
         encoder_features = self.BackboneNeck([encoder_features], training=training)
         encoder_features, positional_encoding = self.ImageEncoderAttention([encoder_features], training=training)
+        image_encoding = encoder_features                         # [B, r, c, D]
         encoder_features, decoder_features, encoder_key, decoder_positional = \
             self.DecoderPrep([encoder_features, positional_encoding], training=training)
 
@@ -102,6 +125,8 @@ class DETR(Model):
                 loss_terms.append(losses_i)
                 self._loss_roots.append(self.loss_fn._losses_tensor)
 
+        if self.PanopticAttention is not None:
+            self._panoptic_inputs = (image_encoding, decoder_features, positional_encoding.value)
         if training:
             self._register(loss_terms, metrics_i)
             return y_pred_i

@@ -80,6 +80,9 @@ class SGD:
 
     def build(self, variables: List[Variable]) -> None:
         dev = device()
+        # momentum survives a rebuild for every variable that stays trainable (Keras keeps one slot variable per weight:
+        # freezing the backbone and unfreezing it later, Boosted_DETR_COCO.ipynb cell 30, does not reset the others' velocity)
+        old_mom = {id(v): m for v, m in zip(getattr(self, "vars", []), getattr(self, "mom_views", []))}
         self.release()
         self.vars = list(variables)
         sizes = [v.value.numel() for v in self.vars]
@@ -88,6 +91,10 @@ class SGD:
         self.flat_mom = torch.zeros(int(offs[-1]), dtype=torch.float32, device=dev)
         self.grad_views = [self.flat_grad[int(o): int(o) + s].view(v.value.shape) for o, s, v in zip(offs[:-1], sizes, self.vars)]
         mom_views = [self.flat_mom[int(o): int(o) + s] for o, s in zip(offs[:-1], sizes)]
+        for v, m in zip(self.vars, mom_views):
+            if id(v) in old_mom and old_mom[id(v)].numel() == m.numel():
+                m.copy_(old_mom[id(v)])
+        self.mom_views = mom_views
         ptrs = np.zeros((len(self.vars), 3), np.uint64)
         for i, v in enumerate(self.vars):
             ptrs[i] = (v.value.data_ptr(), self.grad_views[i].data_ptr(), mom_views[i].data_ptr())
@@ -163,12 +170,18 @@ class DataParallel:
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.overlap = os.environ.get("BDETR_DP_OVERLAP", "1") != "0"
+        # a one-rank process group still runs every collective when asked to (tests/test_dp_gpu.py: the RCCL branch - comm
+        # stream, event waits, async handles - executes on the one-GPU box over a real "nccl" communicator of size 1)
+        self.active = dist.is_initialized() and (self.world > 1 or os.environ.get("BDETR_DP_FORCE", "0") == "1")
         self._flat = None
         self._comm_stream = None
+        self.profile = False             # bench.py: time every bucket's all-reduce with events on the communication stream
+        self._prof_events: List[tuple] = []
+        self.prof_steps: List[dict] = []
 
     # -- plain path (also the gloo CPU tests) ---------------------------------------------------------------
     def allreduce_(self, flat: torch.Tensor) -> None:
-        if self.world == 1:
+        if not self.active:
             return
         handles = []
         for o in range(0, flat.numel(), self.BUCKET_ELEMS):
@@ -205,7 +218,7 @@ class DataParallel:
 
     def begin_step(self, optimizer: "SGD", main_stream, side_stream) -> None:
         self._active = False
-        if self.world == 1 or not self.overlap or getattr(optimizer, "flat_grad", None) is None:
+        if not self.active or not self.overlap or getattr(optimizer, "flat_grad", None) is None:
             return
         self.prepare(optimizer)
         self._seen = {}
@@ -215,6 +228,10 @@ class DataParallel:
         self._main, self._side = main_stream, side_stream
         if self._comm_stream is None and self._flat.is_cuda:
             self._comm_stream = torch.cuda.Stream(device=self._flat.device)
+        self._prof_events = []
+        if self.profile and self._flat.is_cuda:
+            self._prof_base = torch.cuda.Event(enable_timing=True)
+            self._prof_base.record(self._comm_stream)
         self._active = True
 
     def _launch(self, b: int) -> None:
@@ -230,7 +247,17 @@ class DataParallel:
                     ev.record(st)
                     comm.wait_event(ev)
             with torch.cuda.stream(comm):
+                e0 = None
+                if self.profile:
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e0.record(comm)          # behind the waits above: the bucket's gradients are complete when this fires
                 self._handles.append(self.dist.all_reduce(self._flat[lo:hi], op=self.dist.ReduceOp.SUM, async_op=True))
+                if self.profile:
+                    # the collective runs on the backend's own stream: its end is visible on `comm` only through the handle
+                    self._handles[-1].wait()
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record(comm)
+                    self._prof_events.append((e0, e1, (hi - lo) * 4))
         else:
             self._handles.append(self.dist.all_reduce(self._flat[lo:hi], op=self.dist.ReduceOp.SUM, async_op=True))
 
@@ -261,8 +288,19 @@ class DataParallel:
 
     def finish(self, flat: torch.Tensor) -> None:
         """All-reduce whatever ``grad_ready`` did not launch, then make the current stream wait for every bucket."""
-        if self.world == 1:
+        if not self.active:
             return
+        if getattr(self, "_active", False) and flat is not self._flat:
+            # The step was armed on another buffer (the optimizer was rebuilt between begin_step and here).  Buckets already
+            # in flight reduce a retired buffer: wait for them, then refuse - reducing `flat` again on top would double-count
+            # whatever was copied out of the old one.  Model.forward_backward rebuilds the optimizer BEFORE arming the step, so
+            # this is a programming error, not a state a training run reaches.
+            launched = any(self._launched)
+            for h in self._handles:
+                h.wait()
+            self._handles, self._active = [], False
+            if launched:
+                raise RuntimeError("data-parallel step: the optimizer's gradient buffer changed while bucket all-reduces were in flight")
         if not getattr(self, "_active", False) or flat is not self._flat:
             self.allreduce_(flat)
             return
@@ -277,22 +315,50 @@ class DataParallel:
         if flat.is_cuda:
             torch.cuda.current_stream().wait_stream(self._comm_stream)
         self._handles = []
+        if self.profile and self._prof_events:
+            self.prof_steps.append({"base": self._prof_base, "buckets": self._prof_events})
+            self._prof_events = []
+
+    def profile_summary(self) -> Optional[dict]:
+        """Per-step all-reduce time on the communication stream (union of the buckets' [start, end] intervals: buckets queue
+        behind each other) and bandwidths, over the steps recorded while `profile` was on.  Synchronises the device."""
+        if not self.prof_steps:
+            return None
+        torch.cuda.synchronize()
+        busy_ms, nbytes, nbuckets = 0.0, 0, 0
+        for st in self.prof_steps:
+            iv = sorted((st["base"].elapsed_time(e0), st["base"].elapsed_time(e1)) for e0, e1, _ in st["buckets"])
+            end = -1.0
+            for a, b in iv:
+                a = max(a, end)
+                if b > a:
+                    busy_ms += b - a
+                    end = b
+            nbytes += sum(n for _, _, n in st["buckets"])
+            nbuckets += len(st["buckets"])
+        n = len(self.prof_steps)
+        self.prof_steps = []
+        alg = nbytes / (busy_ms * 1e-3) / 1e9 if busy_ms > 0 else 0.0
+        return {"steps": n, "allreduce_ms_per_step": round(busy_ms / n, 4), "bytes_per_step": nbytes // n, "buckets_per_step": nbuckets // n,
+                "algbw_GBps": round(alg, 2), "busbw_GBps": round(alg * 2.0 * (self.world - 1) / max(self.world, 1), 2),
+                "note": "events on the communication stream around each ~32 MB bucket (start = its gradients complete, end = the handle's "
+                        "wait); busbw = algbw * 2 (R - 1) / R (ring all-reduce convention)"}
 
     def broadcast_variables(self, variables: List[Variable]) -> None:
         """Replicas start from rank 0's values (weights AND moving statistics), like MirroredStrategy's mirrored
         variables (parameters.py:74)."""
-        if self.world == 1:
+        if not self.active:
             return
         for v in variables:
             self.dist.broadcast(v.value, src=0)
 
     def barrier(self) -> None:
-        if self.world > 1:
+        if self.active:
             self.dist.barrier()
 
     def any_(self, flag: torch.Tensor) -> None:
         """flag <- max over replicas (the range guard: a replica that skips its update must make all of them skip)."""
-        if self.world > 1:
+        if self.active:
             self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX)
 
 
@@ -369,12 +435,17 @@ class Model(Layer):
         self.validate_matching = False      # fit() turns this on: it synchronises every step anyway (host logging)
         # Range guard of the 'split' policy: the f16 pairs of its forward products hold |x| < 65504, the reference's
         # fp32 does not overflow there.  Producers raise a device flag instead of feeding NaN downstream; while it is
-        # up the optimizer applies nothing and moving statistics stay put.  Every `guard_check_every` steps (every
-        # step under fit(), which synchronises anyway) the host reads the flag and redoes the batch on the
-        # exact-fp32 forward ('mixed').
-        self.guard_check_every = 50
-        self.range_redos = 0
+        # up the optimizer applies nothing and moving statistics stay put.  The host learns of it WITHOUT synchronising:
+        # every step ends with an asynchronous 4-byte copy of the flag into pinned memory, and the next step looks at the
+        # snapshots whose copies have completed (`_guard_poll`).  Every batch from the one that raised the flag on is then
+        # redone on the exact-fp32 forward ('mixed') and the step / learning-rate counters are rolled back for the
+        # update-free attempts, so no batch is lost and the schedule does not run ahead.
+        self.guard_check_every = 1       # 0 disables the host side of the guard
+        self.range_redos = 0             # guarded steps that were redone on the exact-fp32 forward
+        self.range_skipped = 0           # ... how many update-free attempts that covered (counters rolled back for each)
         self._guard_count = 0
+        self._guard_pending: List[tuple] = []      # (step's batch, pinned snapshot of the flag after that step, its copy event)
+        self._guard_was = None
         self.use_graph = os.environ.get("BDETR_GRAPH", "0") == "1"      # capture train_step as a hipGraph (see _graph_step)
         self._graphs, self._graph_warm = {}, {}
 
@@ -402,6 +473,7 @@ class Model(Layer):
             if optimizer is None or getattr(v, "_grad_flat", None) is not getattr(optimizer, "flat_grad", None):
                 v.grad_buf, v._grad_flat = None, None
         self.optimizer = optimizer
+        self._graphs, self._graph_warm = {}, {}      # captured steps update through the retired optimizer's buffers
 
     def distribute(self) -> "Model":
         """Enable data parallelism over the initialised torch.distributed (RCCL) process group."""
@@ -425,9 +497,21 @@ class Model(Layer):
             v.reset_grad()
         live = None
         if self.optimizer is not None and getattr(self.optimizer, "flat_grad", None) is not None:
+            # The trainable set changed since the buffer was built (layer.trainable = False / True between steps): rebuild
+            # NOW, before the buffer is zeroed and before the data-parallel step is armed on it - otherwise early bucket
+            # all-reduces would run on a buffer that stage_gradients is about to retire (and be repeated on the new one).
+            tv_ids = [id(v) for v in self.trainable_variables]
+            if self.optimizer._built_for is not None and self.optimizer._built_for != tv_ids:
+                self.optimizer.build(self.trainable_variables)
             live = self.optimizer.flat_grad
             live.zero_()                         # ONE memset for all gradients (split-K GEMMs accumulate into zeros)
         ops.set_live_flat_grad(live)             # in-place gradient sinks are valid for slices of THIS buffer only
+        guarded = self._guarded()
+        if self._guard_was is not None and self._guard_was != guarded:
+            K.overflow_flag().zero_()            # a flag left up by a step under another policy must not freeze this one's statistics
+            self._guard_pending = []
+        self._guard_was = guarded
+        K.set_guard_active(guarded)              # BatchNorm statistics watch the flag only while somebody reads and clears it
         if self._dp is not None:
             from .engine import side_stream
             self._dp.begin_step(self.optimizer, torch.cuda.current_stream(), side_stream())
@@ -488,7 +572,19 @@ class Model(Layer):
             return None
         if not all(isinstance(v, torch.Tensor) and v.is_cuda for v in data.values()):
             return None
-        return tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(data.items())) + (self.train_gemm_precision,)
+        return tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(data.items())) + (self.train_gemm_precision,) + self._graph_env()
+
+    def _graph_env(self) -> tuple:
+        """Everything a captured step bakes in besides its input shapes: the optimizer object and the variables its flat
+        buffers were built for, the trainable set, dropout rates and loss weights.  A change makes a new signature, i.e. a
+        fresh capture (after two eager steps) - never a replay that keeps training frozen layers or updates a retired buffer."""
+        from . import transformers
+        lf = getattr(self, "loss_fn", None)
+        loss = tuple(getattr(lf, k, None) for k in ("category_weight", "attribute_weight", "box_weight", "exist_weight", "loss_scale"))
+        opt = self.optimizer
+        hyper = (opt.momentum, opt.nesterov, opt.clipnorm) if opt is not None else ()
+        return (id(opt), tuple(getattr(opt, "_built_for", None) or ()), tuple(id(v) for v in self.trainable_variables),
+                transformers.AttentionBlock.dropout_rate, transformers.FeedForwardBlock.dropout_rate, loss, hyper)
 
     def _device_step(self, data: dict, stage_scalars: bool) -> Dict[str, list]:
         """Everything of a training step that runs on the device; no host synchronisation."""
@@ -547,19 +643,61 @@ class Model(Layer):
     def train_step(self, data: dict) -> Dict[str, torch.Tensor]:
         logs = self._train_step_once(data)
         if self._guarded() and self.guard_check_every:
-            self._guard_count += 1
-            if self._guard_count % self.guard_check_every == 0 and K.read_and_clear_overflow():       # host sync
-                import sys
-                self.range_redos += 1
-                print(f"[boosted_detr_amd] step {self.steps_done}: the split-fp16 forward left its range (|x| >= 65504) or went "
-                      f"non-finite; no update was applied since the flag rose - redoing this batch on the exact-fp32 forward", file=sys.stderr)
-                self.steps_done -= 1                     # the guarded attempt applied nothing: it is not a step
-                self.optimizer.iterations -= 1
-                keep, self.train_gemm_precision = self.train_gemm_precision, "mixed"
-                try:
-                    logs = self._train_step_once(data)
-                finally:
-                    self.train_gemm_precision = keep
+            logs = self._guard_poll(data, logs, force=getattr(self, "_guard_force", False))
+        return logs
+
+    GUARD_LAG = 2        # steps between a snapshot and the host's look at it
+
+    def _guard_poll(self, data: dict, logs, force: bool = False):
+        """Host side of the range guard without stalling the device: every step ends with an asynchronous 4-byte copy of the
+        flag into pinned memory; step t looks at the snapshot of step t - GUARD_LAG, whose copy has long landed (the wait on
+        its event only bounds how far the host runs ahead).  A fixed lag, not a poll, so that data-parallel replicas - whose
+        flags agree after the step's MAX all-reduce - take the same decision at the same step.  A raised snapshot names the
+        step that left the fp16 range; that batch and the later ones ran without an update (the optimizer skips while the
+        flag is up), so all of them are redone on the exact-fp32 forward and the counters are rolled back for the
+        update-free attempts.  force: resolve every outstanding snapshot now (fit() reads the logs on the host anyway)."""
+        snap = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        snap.copy_(K.overflow_flag(), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._guard_pending.append((data, snap, ev))
+        return self._guard_resolve(logs, 0 if force else self.GUARD_LAG)
+
+    def _guard_resolve(self, logs, keep: int):
+        while len(self._guard_pending) > keep:
+            _, sn, e = self._guard_pending[0]
+            e.synchronize()
+            if int(sn[0]) != 0:
+                return self._guard_redo(0, logs)
+            self._guard_pending.pop(0)
+        return logs
+
+    def guard_flush(self):
+        """Resolve the snapshots still in flight (end of a run / before reading counters).  Returns the redone step's logs or None."""
+        if self._guarded() and self._guard_pending:
+            return self._guard_resolve(None, 0)
+        return None
+
+    def _guard_redo(self, first_bad: int, logs):
+        import sys
+        torch.cuda.synchronize()                             # rare: every later attempt has finished (none of them applied an update)
+        batches = [d for d, _, _ in self._guard_pending[first_bad:]]
+        self._guard_pending = []
+        K.overflow_flag().zero_()
+        n = len(batches)
+        self.range_redos += 1
+        self.range_skipped += n
+        self.steps_done -= n                                 # update-free attempts are not steps: dropout seeds and the
+        self.optimizer.iterations -= n                       # learning-rate schedule continue from the last applied update
+        print(f"[boosted_detr_amd] step {self.steps_done}: the split-fp16 forward left its range (|x| >= 65504) or went non-finite; "
+              f"no update was applied since - redoing {n} batch(es) on the exact-fp32 forward", file=sys.stderr)
+        keep, self.train_gemm_precision = self.train_gemm_precision, "mixed"
+        try:
+            for d in batches:
+                logs = self._train_step_once(d)
+        finally:
+            self.train_gemm_precision = keep
+        K.overflow_flag().zero_()                            # (bn_stats may have re-raised it for a genuinely non-finite batch statistic)
         return logs
 
     def _train_step_once(self, data: dict) -> Dict[str, torch.Tensor]:
@@ -625,7 +763,8 @@ class Model(Layer):
         history = {"loss": []}
         self.stop_training = False
         self.validate_matching = True
-        self.guard_check_every = 1            # every step ends in a host read of the logs anyway
+        self.guard_check_every = 1
+        self._guard_force = True              # every step ends in a host read of the logs anyway: resolve the guard snapshot at once
         for epoch in range(epochs):
             t0, n, sums = time.time(), 0, {}
             for step, batch in enumerate(x):

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define BDETR_ABI_VERSION 4
+#define BDETR_ABI_VERSION 5
 
 int         bdetr_abi_version(void);
 const char* bdetr_last_error(void);
@@ -51,7 +51,10 @@ int         bdetr_stream_priority_range(int* least, int* greatest);
  *                     accumulator), three products on v_mfma_f32_32x32x16_f16 - fp32-grade products
  *                     (~2^-23), but forward operands must stay below 65504 in magnitude (a larger
  *                     value yields NaN).
- * The env variable BDETR_GEMM_PRECISION=fp32|bf16x3|mixed|split picks the initial value. */
+ * The env variable BDETR_GEMM_PRECISION=fp32|bf16x3|mixed|split picks the initial value.
+ * This policy is the library's ONE piece of mutable state (a mode word like a rounding mode, not data): it is thread-local,
+ * so a host thread's launches are unaffected by another thread's policy, and every launch reads it once on the host at
+ * enqueue time - kernels already enqueued (or captured into a hipGraph) keep the arithmetic they were enqueued with. */
 enum { BDETR_GEMM_FP32 = 0, BDETR_GEMM_BF16X3 = 1, BDETR_GEMM_MIXED = 2, BDETR_GEMM_SPLIT = 3 };
 int         bdetr_set_gemm_precision(int mode);
 int         bdetr_get_gemm_precision(void);
@@ -194,8 +197,6 @@ typedef struct {
     const uint64_t* relu_mask;      /* may be null; else out = relu(bn(y) + shortcut): the ReLU decision is bdetr_bn_apply_p16's bit mask (1x1 convs only) */
 } bdetr_bn_bwd_fuse;
 int bdetr_p16_conv2d_bwd_data_stat_chunks(const bdetr_conv_desc* d);
-/* diagnostic (BDETR_SGEMM_DBG bit 32): cycle stamps of one workgroup's first K-steps; see tools/kstep_stamps.py */
-int bdetr_sgemm_debug_stamps(uint64_t* out, int n);
 /* x <- x * relu_mask in place (n elements, n % 4 == 0): materialises a gradient that was handed on with its unit's ReLU mask
  * still to be applied, for consumers other than bdetr_p16_conv2d_bwd_data_masked_accum / bdetr_bn_bwd_p16(out_p16 = 2). */
 int bdetr_relu_mask_apply(float* x, const uint64_t* relu_mask, int64_t n, void* stream);

@@ -139,3 +139,87 @@ def test_two_replicas_config2_batch32_overlapped_allreduce(cuda, tmp_path):
     assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
     assert "DP_CFG2_OK" in outs[0], outs[0][-2000:]
     print(outs[0].strip().splitlines()[-1])
+
+
+_WORKER_RCCL1 = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from test_training_gpu import small_model, small_batch
+from boosted_detr_amd.training import SGD
+from boosted_detr_amd.engine import to_device
+cfg, host = small_batch()
+batch = {"image": to_device(host["image"]), "category": to_device(host["category"], torch.int32), "attribute": to_device(host["attribute"], torch.int32),
+         "bbox": to_device(host["bbox"]), "num_objects": to_device(host["num_objects"], torch.int32)}
+def run(distributed):
+    m = small_model()
+    m.compile(optimizer=SGD(1e-2, momentum=.9, nesterov=True, clipnorm=.1))
+    if distributed:
+        m.distribute()
+        assert m._dp.active and m._dp.world == 1 and m.loss_fn.loss_scale == 1.0
+        m._dp.BUCKET_ELEMS = 2 * 1024 * 1024            # several buckets on this small model
+    losses = [m.logs_to_host(m.train_step(batch))["loss"] for _ in range(5)]
+    torch.cuda.synchronize()
+    return m, losses
+ref, want = run(False)
+m, got = run(True)
+dp = m._dp
+assert dp._comm_stream is not None and dp._expected is not None and len(dp._bounds) >= 3, (dp._comm_stream, len(dp._bounds))
+# freeze -> step -> unfreeze -> step with early launches armed (the advisor's scenario): the optimizer is rebuilt before the
+# step is armed, no bucket is reduced twice, nothing raises
+m.EncoderBackbone.trainable = False; ref.EncoderBackbone.trainable = False
+for _ in range(3):
+    got.append(m.logs_to_host(m.train_step(batch))["loss"]); want.append(ref.logs_to_host(ref.train_step(batch))["loss"])
+m.EncoderBackbone.trainable = True; ref.EncoderBackbone.trainable = True
+for _ in range(3):
+    got.append(m.logs_to_host(m.train_step(batch))["loss"]); want.append(ref.logs_to_host(ref.train_step(batch))["loss"])
+torch.cuda.synchronize()
+# a one-rank all-reduce is the identity: the distributed run tracks the plain one (float atomics of the split-K weight
+# gradients make any two runs differ in the last bits; a 2-image toy amplifies that along the trajectory)
+assert all(np.isfinite(got)), got
+assert all(abs(a - b) <= 2e-3 * abs(b) for a, b in zip(got[:4], want[:4])), (got, want)
+assert all(abs(a - b) <= 5e-2 * abs(b) for a, b in zip(got, want)), (got, want)
+dp.profile = True
+for _ in range(2):
+    m.train_step(batch)
+summary = dp.profile_summary()
+assert summary is not None and summary["buckets_per_step"] >= 3 and summary["allreduce_ms_per_step"] > 0, summary
+flag = torch.zeros(1, dtype=torch.int32, device="cuda"); dp.any_(flag); dp.broadcast_variables(m.variables[:3]); dp.barrier()
+print("RCCL_ONE_RANK_OK rccl", ".".join(str(x) for x in torch.cuda.nccl.version()), "buckets", len(dp._bounds), summary)
+dist.destroy_process_group()
+'''
+
+
+def test_rccl_branch_runs_on_a_one_rank_communicator(cuda, tmp_path):
+    """The device branch of the data-parallel path - init_process_group("nccl", device_id=...), the communication stream, event
+    waits on the main and side streams, async handles, the MAX all-reduce of the range guard, the weight broadcast - had only
+    ever executed over gloo.  One rank over a real RCCL communicator runs all of it on this box's GPU (BDETR_DP_FORCE=1 keeps
+    the collectives on although world_size is 1), through a freeze / unfreeze cycle with early bucket launches armed."""
+    script = tmp_path / "rccl1.py"
+    script.write_text(_WORKER_RCCL1)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29551", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", BDETR_DP_FORCE="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0 and "RCCL_ONE_RANK_OK" in p.stdout, p.stdout[-3000:]
+    print(p.stdout.strip().splitlines()[-1])
+
+
+def test_bench_multi_rank_code_path_over_one_rank_rccl(cuda):
+    """bench.py's N > 1 branch (nccl init with device_id, distribute(), barriers, max-over-ranks timing, per-bucket all-reduce
+    timing) on a one-rank RCCL communicator: the line must carry what the driver's 8-GPU run will be checked against."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29553", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", BDETR_DP_FORCE="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-roofline",
+                        "--no-batch32", "--no-fp32-policy"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    d = line["config"]["distributed"]
+    assert d["backend"] == "nccl" and d["world_size"] == 1 and d["rccl_version"], d
+    assert line["config"]["env_overrides"] == {"BDETR_DP_FORCE": "1"}, line["config"]["env_overrides"]
+    ar = line["allreduce"]
+    assert ar and ar["buckets_per_step"] >= 3 and 120e6 < ar["bytes_per_step"] < 130e6 and ar["allreduce_ms_per_step"] > 0, ar       # 31.0 M fp32 gradients
+    assert line["range_guard"]["overflow_flag_after_run"] == 0 and line["range_guard"]["range_redos_in_timed_region"] == 0
+    assert line["value"] > 100 and line["config"]["step_launch"] == "eager"
+    print({k: ar[k] for k in ("allreduce_ms_per_step", "algbw_GBps", "buckets_per_step")}, "images/s", line["value"])

@@ -139,6 +139,45 @@ for step in range(4):
         got = flat[int(offs[i]): int(offs[i]) + sz]
         assert torch.all(got == want), (step, i, float(got[0]), want)
     assert (early > 0) == (step >= 1), (step, early)        # step 0 calibrates the contribution counts, later steps overlap
+# The trainable set changed (freeze / unfreeze): Model.forward_backward rebuilds the optimizer BEFORE begin_step, so the step is
+# armed on the new buffer, runs one calibration step without early launches, then overlaps again - every sum right throughout.
+keep = [0, 2, 4]
+sizes2 = [sizes[i] for i in keep]
+offs2 = np.concatenate([[0], np.cumsum(sizes2)])
+flat2 = torch.zeros(int(offs2[-1]))
+vs2 = []
+for j, i in enumerate(keep):
+    q = vs[i]; q.grad_buf = flat2[int(offs2[j]): int(offs2[j]) + sizes2[j]]; q.grad = None; q._grad_flat = flat2
+    vs2.append(q)
+opt.flat_grad = flat2; opt.vars = vs2
+for step in range(3):
+    flat2.zero_()
+    dp2.begin_step(opt, None, None)
+    early = 0
+    for j in reversed(range(len(vs2))):
+        q = vs2[j]
+        q.grad_buf.copy_(torch.full((sizes2[j],), float((dp2.rank + 1) * (j + 1) + step)))
+        q.grad = q.grad_buf
+        dp2.grad_ready(q)
+        early = max(early, sum(dp2._launched)) if dp2._expected is not None and dp2._active else early
+    dp2.finish(flat2)
+    for j, sz in enumerate(sizes2):
+        want = sum((r + 1) * (j + 1) + step for r in range(dp2.world))
+        assert torch.all(flat2[int(offs2[j]): int(offs2[j]) + sz] == want), ("rebuilt", step, j)
+    assert (early > 0) == (step >= 1), ("rebuilt", step, early)
+# ... and the state the advisor described (armed on a buffer that is then retired, buckets already in flight) is refused
+# loudly instead of reducing twice: every rank raises, after waiting for the handles it launched
+flat2.zero_()
+dp2.begin_step(opt, None, None)
+for j in reversed(range(len(vs2))):
+    vs2[j].grad = vs2[j].grad_buf
+    dp2.grad_ready(vs2[j])
+assert any(dp2._launched)
+try:
+    dp2.finish(torch.zeros(int(offs2[-1])))
+    raise SystemExit("finish() accepted a retired buffer")
+except RuntimeError as e:
+    assert "gradient buffer changed" in str(e), e
 dist.barrier(); dist.destroy_process_group()
 print("rank", dp.rank, "ok")
 '''
@@ -155,3 +194,92 @@ def test_data_parallel_allreduce_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert all("ok" in o for o in outs)
+
+
+def test_data_parallel_cuda_branch_with_fake_streams(monkeypatch):
+    """The device branch of DataParallel._launch / finish (communication stream, event waits on the main and side streams,
+    async handles, the join) cannot run here - there is no GPU - and on the one-GPU box it runs over a one-rank RCCL
+    communicator (tests/test_dp_gpu.py).  This drives the same code with recording fakes for torch.cuda and
+    torch.distributed and checks the ORDER of operations: a bucket's collective is enqueued on the communication stream only
+    after that stream waits for events recorded on BOTH producer streams, nothing waits for the collective until finish(),
+    and finish() waits for every handle before the current stream joins the communication stream."""
+    import types
+    import torch
+    from boosted_detr_amd import training
+    log = []
+
+    class FakeStream:
+        def __init__(self, name): self.name = name
+        def wait_event(self, ev): log.append(("wait_event", self.name, ev.on))
+        def wait_stream(self, other): log.append(("wait_stream", self.name, other.name))
+
+    class FakeEvent:
+        def __init__(self, enable_timing=False): self.on = None
+        def record(self, st=None): self.on = (st or cur[0]).name; log.append(("record", self.on))
+
+    class FakeCtx:
+        def __init__(self, st): self.st = st
+        def __enter__(self): self.prev, cur[0] = cur[0], self.st
+        def __exit__(self, *a): cur[0] = self.prev
+
+    main, side, comm = FakeStream("main"), FakeStream("side"), FakeStream("comm")
+    cur = [main]
+    fake_cuda = types.SimpleNamespace(Stream=lambda device=None: comm, Event=FakeEvent, stream=lambda st: FakeCtx(st),
+                                      current_stream=lambda: cur[0], synchronize=lambda: None)
+    monkeypatch.setattr(training.torch, "cuda", fake_cuda)
+
+    class Handle:
+        def __init__(self, n): self.n = n
+        def wait(self): log.append(("handle_wait", self.n, cur[0].name))
+
+    class FakeDist:
+        class ReduceOp: SUM = "sum"; MAX = "max"
+        @staticmethod
+        def is_initialized(): return True
+        @staticmethod
+        def get_world_size(): return 2
+        @staticmethod
+        def get_rank(): return 0
+        @staticmethod
+        def all_reduce(t, op=None, async_op=False):
+            log.append(("all_reduce", t.numel(), cur[0].name)); return Handle(t.numel())
+    monkeypatch.setitem(sys.modules, "torch.distributed", FakeDist)
+    monkeypatch.setattr(torch, "distributed", FakeDist, raising=False)
+
+    class FlatOnDevice:                      # a flat buffer that says it lives in HBM
+        is_cuda, device = True, "cuda:0"
+        def __init__(self, n, base=4096): self.n, self.base = n, base
+        def numel(self): return self.n
+        def data_ptr(self): return self.base
+        def __getitem__(self, sl): return FlatOnDevice(sl.stop - sl.start, self.base + 4 * sl.start)
+
+    class V: pass
+    flat = FlatOnDevice(2500)
+    sizes, vs, off = [1200, 800, 500], [], 0
+    for i, sz in enumerate(sizes):
+        v = V(); v.name = f"v{i}"; v.grad_buf = flat[off: off + sz]; v.grad = v.grad_buf; v._grad_flat = flat
+        vs.append(v); off += sz
+    opt = types.SimpleNamespace(flat_grad=flat, vars=vs)
+    dp = training.DataParallel()
+    dp.BUCKET_ELEMS = 1000
+    assert dp.active and dp.world == 2
+    for step in range(2):                    # step 0 learns the contribution counts, step 1 launches from grad_ready
+        log.clear()
+        dp.begin_step(opt, main, side)
+        for v in reversed(vs):
+            dp.grad_ready(v)
+        early = [e for e in log if e[0] == "all_reduce"]
+        assert (len(early) > 0) == (step == 1), (step, log)
+        assert not any(e[0] == "handle_wait" for e in log)                   # nothing waits before finish()
+        dp.finish(flat)
+        ar = [i for i, e in enumerate(log) if e[0] == "all_reduce"]
+        assert len(ar) == 3 and all(log[i][2] == "comm" for i in ar)         # 3 buckets, all enqueued on the communication stream
+        for i in ar:                                                         # ... each behind waits for main AND side
+            pre = log[max(0, i - 4): i]
+            assert ("wait_event", "comm", "main") in pre and ("wait_event", "comm", "side") in pre, (i, log)
+        waits = [i for i, e in enumerate(log) if e[0] == "handle_wait"]
+        join = log.index(("wait_stream", "main", "comm"))
+        assert len(waits) == 3 and max(waits) < join and min(waits) > max(ar)
+    flag = torch.zeros(1)
+    dp.any_(flag)
+    assert log[-1] == ("all_reduce", 1, "main")

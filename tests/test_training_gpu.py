@@ -246,7 +246,7 @@ def test_range_guard_redoes_an_overflowing_step_on_the_fp32_forward(cuda):
         m.forward_backward(batch)                       # build (on the range-safe policy)
         m.set_weights_dict(params)
         m.train_gemm_precision = policy
-        m.guard_check_every = 1
+        m._guard_force = True                           # resolve the step's flag snapshot at once (what fit() does)
         return m
 
     k.read_and_clear_overflow()
@@ -266,6 +266,94 @@ def test_range_guard_redoes_an_overflowing_step_on_the_fp32_forward(cuda):
         scale = np.abs(b[key]).max() + 1e-12
         assert np.abs(a[key] - b[key]).max() <= 1e-4 * scale, key      # weights and downstream moving statistics: one update, from the redo
     assert m.optimizer.iterations == 1 and m.steps_done == 1           # the guarded attempt applied nothing and is not counted
+
+    # The same outside fit(): the host looks at a step's snapshot GUARD_LAG steps later, without synchronising.  Every batch
+    # since the flag rose ran without an update; all of them are redone and the counters are rolled back - three overflowing
+    # steps end exactly where three 'mixed' steps end (no batch lost, the learning-rate schedule not ahead).
+    ref3, lag = fresh("mixed"), fresh("split")
+    lag._guard_force = False
+    for _ in range(3):
+        w3 = ref3.logs_to_host(ref3.train_step(batch))
+        g3 = lag.train_step(batch)
+    assert lag.range_redos == 1 and lag.range_skipped == 3 and lag.GUARD_LAG == 2
+    assert lag.optimizer.iterations == 3 and lag.steps_done == 3 and not k.read_and_clear_overflow()
+    g3 = lag.logs_to_host(g3)
+    assert abs(g3["loss"] - w3["loss"]) <= 1e-3 * abs(w3["loss"]), (g3, w3)
+    a, b = lag.get_weights_dict(), ref3.get_weights_dict()
+    for key in a:
+        if not any(u in key for u in upstream):
+            assert np.abs(a[key] - b[key]).max() <= 1e-3 * (np.abs(b[key]).max() + 1e-12), key
+    assert lag.guard_flush() is None and lag.range_redos == 1         # nothing left in flight is raised
+
+
+def test_a_stale_overflow_flag_does_not_freeze_moving_statistics_under_another_policy(cuda):
+    """The flag is process-global.  Left up by a guarded step that nobody polled (or by a stray pack of a tool), it must not stop
+    the BatchNorm moving statistics of later 'mixed' / 'fp32' steps, which never read or clear it."""
+    from boosted_detr_amd import kernels as k
+    from boosted_detr_amd.training import SGD
+    cfg, batch = small_batch()
+    m = small_model()
+    m.compile(optimizer=SGD(1e-3, momentum=0.9, nesterov=True, clipnorm=0.1))
+    m.train_gemm_precision = "mixed"
+    m.train_step(batch)
+    k.overflow_flag().fill_(1)                                   # as an unpolled overflow would leave it
+    name = "EncoderBackbone/resnet50/conv3_block1_1_bn/moving_mean"
+    before = m.get_weights_dict()[name].copy()
+    m.train_step(batch)
+    after = m.get_weights_dict()[name]
+    assert np.abs(after - before).max() > 0, "moving statistics stopped updating"
+    k.read_and_clear_overflow()
+
+
+def test_freeze_after_capture_does_not_replay_the_old_graph(cuda):
+    """A captured step bakes in the trainable set, the optimizer's buffers, dropout rates and loss weights: changing any of
+    them must lead to a fresh capture, never to a replay that keeps training a frozen layer (Model._graph_env)."""
+    from boosted_detr_amd.engine import to_device
+    from boosted_detr_amd.training import SGD
+    cfg, host = small_batch()
+    batch = {"image": to_device(host["image"]), "category": to_device(host["category"], torch.int32), "attribute": to_device(host["attribute"], torch.int32),
+             "bbox": to_device(host["bbox"]), "num_objects": to_device(host["num_objects"], torch.int32)}
+    m = small_model()
+    m.compile(optimizer=SGD(1e-2, momentum=0.9, nesterov=True, clipnorm=0.1))
+    m.use_graph = True
+    for _ in range(4):
+        m.train_step(batch)
+    assert len(m._graphs) == 1
+    m.EncoderBackbone.trainable = False
+    w0 = {v.name: v.value.clone() for v in m.EncoderBackbone.variables if v.trainable}
+    h0 = m.CategoryPredictionHead.DenseOut.kernel.value.clone()
+    for _ in range(4):
+        m.train_step(batch)
+    torch.cuda.synchronize()
+    assert len(m._graphs) == 2                                         # a second capture for the new trainable set
+    for v in m.EncoderBackbone.variables:
+        if v.name in w0:
+            assert torch.equal(v.value, w0[v.name]), v.name            # frozen weights did not move
+    assert not torch.equal(m.CategoryPredictionHead.DenseOut.kernel.value, h0)      # the rest keeps training
+    m.compile(optimizer=SGD(1e-2, momentum=0.9, nesterov=True, clipnorm=0.1))
+    assert not m._graphs                                               # a new optimizer retires every captured step
+    for _ in range(3):
+        logs = m.logs_to_host(m.train_step(batch))
+    assert np.isfinite(logs["loss"])
+
+
+def test_momentum_survives_a_freeze_unfreeze_cycle(cuda):
+    """SGD.build after the trainable set changed keeps the velocity of every variable that stays trainable (Keras slot
+    variables live per weight; Boosted_DETR_COCO.ipynb cell 30 freezes and unfreezes layers between fits)."""
+    from boosted_detr_amd.training import SGD
+    cfg, batch = small_batch()
+    m = small_model()
+    m.compile(optimizer=SGD(1e-2, momentum=0.9, nesterov=True, clipnorm=0.1))
+    for _ in range(2):
+        m.train_step(batch)
+    v = m.CategoryPredictionHead.DenseOut.kernel
+    i = [id(x) for x in m.optimizer.vars].index(id(v))
+    mom = m.optimizer.mom_views[i].clone()
+    assert float(mom.abs().max()) > 0
+    m.EncoderBackbone.trainable = False
+    m.forward_backward(batch)                                          # rebuilds the flat buffers for the smaller set
+    j = [id(x) for x in m.optimizer.vars].index(id(v))
+    assert len(m.optimizer.vars) < 200 and torch.equal(m.optimizer.mom_views[j], mom)
 
 
 def test_graph_replayed_steps_equal_eager_steps(cuda):

@@ -1,6 +1,7 @@
 """Where does a short-K 1x1 layer spend its time?  BDETR_SGEMM_DBG bits: 1 = no C stores, 2 = no K loop (no loads / MFMAs),
 4 = per-element stores from the accumulators (no LDS transposition), 8 = no fragment reads / MFMAs, 16 = no staging loads.
-Diagnostic builds only."""
+Diagnostic builds only: BDETR_CXXFLAGS=-DBDETR_SGEMM_DIAG python -m boosted_detr_amd.build --force (the production library
+never reads BDETR_SGEMM_DBG)."""
 import os
 import sys
 

@@ -1,7 +1,7 @@
 """Cycle stamps of one workgroup's first 12 K-steps of a pre-split 3x3 forward launch (BDETR_SGEMM_DBG=32 is set here):
 per step the time spent waiting for the stage's loads, in the barrier, issuing the next stage, and issuing the MFMAs.
-Needs a diagnostic build of the library: BDETR_CXXFLAGS=-DBDETR_SGEMM_STAMPS python -m boosted_detr_amd.build --force
-(the stamp array is compiled out of the production kernels).  Usage: python tools/kstep_stamps.py [H C K R]"""
+Needs a diagnostic build of the library: BDETR_CXXFLAGS="-DBDETR_SGEMM_DIAG -DBDETR_SGEMM_STAMPS" python -m boosted_detr_amd.build --force
+(the stamp array, its entry point and every BDETR_SGEMM_DBG switch are compiled out of the production library).  Usage: python tools/kstep_stamps.py [H C K R]"""
 import ctypes as C
 import os
 import sys
@@ -22,7 +22,9 @@ for _ in range(3):
     k.p16_conv2d_fwd(xf, wf, None, g, 0, want_stats=False)
 torch.cuda.synchronize()
 buf = (C.c_uint64 * 48)()
-_lib.check(_lib.lib().bdetr_sgemm_debug_stamps(buf, 48), "stamps")
+fn = _lib.lib().bdetr_sgemm_debug_stamps          # diagnostic builds only: not part of include/bdetr.h
+fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_int]
+_lib.check(fn(buf, 48), "stamps")
 t = list(buf)
 print("step  wait_loads  barrier  issue_next  mfma_issue   (cycles; the step's total is the sum + the next step's wait)")
 for kt in range(12):
