@@ -387,7 +387,11 @@ __device__ __forceinline__ void atomic_epilogue(f32x16 (&acc)[BM / WM / 32][BN /
 // vmcnt leaves the younger stages in flight across the (raw) barrier.
 constexpr int default_occ(int bm, int bn, int wm, int wn, int ns) { return (wm * wn == 4 && 2 * lds_bytes_for(bm, bn, ns) <= 160 * 1024) ? 2 : (wm * wn == 8 ? 2 : 1); }
 
-template <int BM, int BN, int WM, int WN, int NS, class LA, class LB, bool XX, bool F16, int OCC = default_occ(BM, BN, WM, WN, NS)>
+// PP ("ping-pong", 8 waves, three-stage ring): the two waves of a SIMD alternate roles in lock step - while waves 0-3 multiply
+// K-step t from fragments already in registers, waves 4-7 read their fragments and issue their share of the LDS-DMA loads, then
+// the halves swap (see the main loop).  A wave's MFMA segment contains nothing but MFMAs and its load segment runs in the shadow
+// of its SIMD partner's MFMAs, instead of both partners stalling on the address unit at the same time.
+template <int BM, int BN, int WM, int WN, int NS, class LA, class LB, bool XX, bool F16, bool PP = false, int OCC = default_occ(BM, BN, WM, WN, NS)>
 __global__ __launch_bounds__(WM * WN * 64, OCC)
 void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
 {
@@ -399,6 +403,7 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
     static_assert(NIA >= 1 && NIB >= 1 && NIA * NW * 1024 == A_BYTES && NIB * NW * 1024 == B_BYTES, "tile / wave count mismatch");
     constexpr int LDS_BYTES = lds_bytes_for(BM, BN, NS);
     static_assert(NS >= 2 && NS <= 4 && LDS_BYTES <= 160 * 1024, "LDS budget");
+    static_assert(BK == 32, "fragment helpers assume two 16-deep MFMA steps per stage");
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
 
     const int tid = threadIdx.x;
@@ -418,8 +423,8 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
     // MFMA-bound, measured equal or slower when persistent, and the f16 128x128 one does not fit its accumulators plus
     // the loop-carried state in 256 VGPRs) and the XX kernels (split-K weight gradients) run one virtual block per
     // workgroup.
-    constexpr bool PERSIST = !XX && std::is_same_v<LA, RRDense>;
-    static_assert(NS == 2, "both loops are written for a two-stage ring");
+    constexpr bool PERSIST = !PP && !XX && std::is_same_v<LA, RRDense>;
+    static_assert(PP ? (NS == 3 && NW == 8) : NS == 2, "the plain loops are written for a two-stage ring, the ping-pong loop for three stages and 8 waves");
     const int nwg = g.tiles_i * g.tiles_j;
     const int total = PERSIST ? nwg : nwg * (int)gridDim.z;
     int vb = PERSIST ? (int)blockIdx.x : (int)(blockIdx.z * nwg + blockIdx.x);
@@ -575,46 +580,127 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
     // order (LDS-DMA writes and ds_reads may alias as far as the compiler knows, so it keeps this order): a load's
     // issue cost (address VALU + M0 + buffer_load ... lds) then hides in the shadow of the preceding MFMAs instead of
     // running as a serial preamble in front of them.
-    auto kstep = [&](int buf) {
-        if (BDETR_DBG(g, 8)) return;                     // diagnostic builds: no fragment reads / MFMAs
+    auto load_frags = [&](int buf, int ks, u32x4 (&ah)[TM], u32x4 (&al)[TM], u32x4 (&bh)[TN], u32x4 (&bl)[TN]) {
         const unsigned char* tA = lds + buf * STAGE_BYTES;
         const unsigned char* tB = tA + A_BYTES;
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            u32x4 ah[TM], al[TM], bh[TN], bl[TN];
+        for (int a = 0; a < TM; ++a) {
+            if constexpr (!XX) frag_rr(tA, wm * WTM + a * 32 + li, ks, ah[a], al[a]);
+            else               frag_xx(tA, BM * 4, wm * WTM + a * 32, ks, ah[a], al[a]);
+        }
 #pragma unroll
-            for (int a = 0; a < TM; ++a) {
-                if constexpr (!XX) frag_rr(tA, wm * WTM + a * 32 + li, ks, ah[a], al[a]);
-                else               frag_xx(tA, BM * 4, wm * WTM + a * 32, ks, ah[a], al[a]);
-            }
+        for (int b = 0; b < TN; ++b) {
+            if constexpr (!XX) frag_rr(tB, wn * WTN + b * 32 + li, ks, bh[b], bl[b]);
+            else               frag_xx(tB, BN * 4, wn * WTN + b * 32, ks, bh[b], bl[b]);
+        }
+    };
+    auto mfma_ks = [&](const u32x4 (&ah)[TM], const u32x4 (&al)[TM], const u32x4 (&bh)[TN], const u32x4 (&bl)[TN]) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
 #pragma unroll
             for (int b = 0; b < TN; ++b) {
-                if constexpr (!XX) frag_rr(tB, wn * WTN + b * 32 + li, ks, bh[b], bl[b]);
-                else               frag_xx(tB, BN * 4, wn * WTN + b * 32, ks, bh[b], bl[b]);
-            }
-#pragma unroll
-            for (int a = 0; a < TM; ++a)
-#pragma unroll
-                for (int b = 0; b < TN; ++b) {
-                    if constexpr (F16) {
+                if constexpr (F16) {
 #define H8(v) __builtin_bit_cast(f16x8, v)
-                        acc2[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(al[a]), H8(bh[b]), acc2[a][b], 0, 0, 0);
-                        acc2[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(ah[a]), H8(bl[b]), acc2[a][b], 0, 0, 0);
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(ah[a]), H8(bh[b]), acc[a][b], 0, 0, 0);
+                    acc2[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(al[a]), H8(bh[b]), acc2[a][b], 0, 0, 0);
+                    acc2[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(ah[a]), H8(bl[b]), acc2[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(ah[a]), H8(bh[b]), acc[a][b], 0, 0, 0);
 #undef H8
-                    } else {
+                } else {
 #define BF8(v) __builtin_bit_cast(bf16x8, v)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF8(al[a]), BF8(bh[b]), acc[a][b], 0, 0, 0);
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF8(ah[a]), BF8(bl[b]), acc[a][b], 0, 0, 0);
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF8(ah[a]), BF8(bh[b]), acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF8(al[a]), BF8(bh[b]), acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF8(ah[a]), BF8(bl[b]), acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF8(ah[a]), BF8(bh[b]), acc[a][b], 0, 0, 0);
 #undef BF8
-                    }
                 }
+            }
+    };
+    // One K-step of the plain loops: fragment reads of one 16-deep half, its MFMAs, then the other half
+    auto kstep = [&](int buf) {
+        if (BDETR_DBG(g, 8)) return;                     // diagnostic builds: no fragment reads / MFMAs
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            u32x4 ah[TM], al[TM], bh[TN], bl[TN];
+            load_frags(buf, ks, ah, al, bh, bl);
+            mfma_ks(ah, al, bh, bl);
         }
     };
 
     // ---------------- main loop ----------------
-    if constexpr (PERSIST) {
+    if constexpr (PP) {
+        // Ping-pong over a three-stage ring.  Group X = waves 0-3, group Y = waves 4-7: wave w and wave w + 4 share a SIMD (a
+        // workgroup's waves are dealt to the SIMDs cyclically), X owns the upper half of the tile's rows, Y the lower half, the B
+        // tile is shared.  K-step t is two half-steps, each closed by ONE workgroup barrier:
+        //   A(t): X multiplies step t (24 MFMAs, fragments already in registers) | Y reads its fragments of stage t and issues its
+        //         share of stage t + 2's loads
+        //   B(t): Y multiplies step t                                            | X reads its fragments of stage t + 1 and issues
+        //         its share of stage t + 2's loads
+        // Ring safety: stage t + 2 overwrites the buffer of stage t - 1, last read in A(t - 1) (by Y), one barrier before the first
+        // issue.  Landing: X's share of stage s is issued in B(s - 2) and waited for (vmcnt(0)) at the end of A(s - 1); Y's share is
+        // issued in A(s - 2) and waited for by the counted vmcnt(NLOAD) at the end of A(s - 1), which leaves Y's newest stage in
+        // flight; the barrier that closes A(s - 1) precedes the first read of stage s (X in B(s - 1)).  Every wave issues every
+        // stage exactly once, in order (the loaders' per-stage state advances once per issue_all).
+        constexpr int NLOAD_ = NIA + NIB;
+        const int nk = (r_end - r_begin + BK - 1) / BK;
+        float bias_pre[TN];
+        gemm_load_bias<BM, BN, WM, WN>(g, j0, bias_pre);              // (older than every stage load: retired by the first counted wait)
+        const bool grpY = wave >= NW / 2;                              // wave-uniform (readfirstlane above): scalar branches
+        u32x4 fah[2][TM], fal[2][TM], fbh[2][TN], fbl[2][TN];
+        auto read_all = [&](auto buf_c) {
+            constexpr int buf = decltype(buf_c)::value;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) load_frags(buf, ks, fah[ks], fal[ks], fbh[ks], fbl[ks]);
+        };
+        auto mfma_step = [&]() {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) mfma_ks(fah[ks], fal[ks], fbh[ks], fbl[ks]);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if (nk > 0) issue_all(0, r_begin);
+        if (nk > 1) issue_all(1, r_begin + BK);
+        if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(NLOAD_) : "memory");
+        else        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (!grpY) read_all(std::integral_constant<int, 0>{});
+        auto step = [&](int t, auto b0_c, auto b1_c, auto b2_c) {
+            constexpr int b2 = decltype(b2_c)::value;
+            // ---- A(t)
+            if (!grpY) {
+                mfma_step();
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            } else {
+                read_all(b0_c);
+                if (t + 2 < nk) {
+                    issue_all(b2, r_begin + (t + 2) * BK);
+                    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(NLOAD_) : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                }
+            }
+            // ---- B(t)
+            if (grpY) {
+                mfma_step();
+            } else {
+                if (t + 1 < nk) read_all(b1_c);
+                if (t + 2 < nk) issue_all(b2, r_begin + (t + 2) * BK);
+            }
+            asm volatile("s_barrier" ::: "memory");
+        };
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+        for (int t = 0; t < nk; t += 3) {                 // unrolled by the ring depth: LDS addresses are lane bases + immediates
+            step(t, I0{}, I1{}, I2{});
+            if (t + 1 < nk) step(t + 1, I1{}, I2{}, I0{});
+            if (t + 2 < nk) step(t + 2, I2{}, I0{}, I1{});
+        }
+        fold_acc2();
+        if (XX && g.mode == ST_ATOMIC && g.bias == nullptr && g.act == BDETR_ACT_NONE && g.stat_sum == nullptr && !g.rowmap && g.ldc * 4 * BM < (1ll << 31)) {
+            atomic_epilogue<BM, BN, WM, WN>(acc, g, i0, j0);
+            return;
+        }
+        gemm_epilogue<BM, BN, WM, WN, NT, LDS_BYTES / 4>(acc, g, reinterpret_cast<float*>(lds), tile_i, i0, j0, g.c, bias_pre);
+    } else if constexpr (PERSIST) {
         // Two-stage ring, persistent over tiles.  Per K-step: wait for everything this wave has in flight (stage kt, and
         // on a tile's first step the previous tile's C stores - on gfx9 stores count in vmcnt and return out of order with
         // loads, so a counted wait cannot tell them apart), barrier (every wave's share of stage kt has landed and every
@@ -718,18 +804,19 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
 // (13.1 ms: equal on the 40x40 3x3 layers, slower on the others).  More bytes in flight or more resident
 // workgroups do not help: at 27 B/clk/CU the staging already runs near the L2 -> LDS fill rate the guide measured for
 // LDS-DMA gathers (66-73 GB/s per CU), which is what a bigger FLOP-per-staged-byte ratio would have to relieve.
-enum { T_128x128 = 0, T_128x64 = 1, T_64x64 = 2, T_COUNT = 3 };
-const int TILE_BM[T_COUNT] = {128, 128, 64};
-const int TILE_BN[T_COUNT] = {128, 64, 64};
-const int TILE_WM[T_COUNT] = {2, 2, 2};
+enum { T_128x128 = 0, T_128x64 = 1, T_64x64 = 2, T_PP256x128 = 3, T_PP256x64 = 4, T_COUNT = 5 };
+const int TILE_BM[T_COUNT] = {128, 128, 64, 256, 256};
+const int TILE_BN[T_COUNT] = {128, 64, 64, 128, 64};
+const int TILE_WM[T_COUNT] = {2, 2, 2, 4, 4};
 
 int forced_tile() {
     static int forced = -2;
     if (forced == -2) {
         forced = -1;
         if (const char* e = getenv("BDETR_STILE")) {
-            const char* names[T_COUNT] = {"128x128", "128x64", "64x64"};
+            const char* names[T_COUNT] = {"128x128", "128x64", "64x64", "pp256x128", "pp256x64"};
             for (int t = 0; t < T_COUNT; ++t) if (!strcmp(e, names[t])) forced = t;
+            if (!strcmp(e, "pp")) forced = T_PP256x128;
         }
     }
     return forced;
@@ -737,8 +824,15 @@ int forced_tile() {
 
 // Bigger tiles stage fewer bytes per FLOP (128x128: 32 FLOP per staged byte, 64x64: 16) but need enough
 // workgroups to fill 256 CUs x 2 resident workgroups.
-int choose_tile(int64_t I, int64_t J, int64_t z) {
-    const int forced = forced_tile();
+// patch = the A operand is an im2col view (3x3 forward / backward-data): the ping-pong tiles exist for those kernels only
+// (pp_ok: bf16 launches only - the f16 flavour's two accumulator sets leave no room for a whole K-step of fragments)
+int choose_tile(int64_t I, int64_t J, int64_t z, bool pp_ok = false) {
+    int forced = forced_tile();
+    if (forced >= T_PP256x128) {
+        const bool patch = pp_ok;
+        if (!patch) forced = -1;                                       // dense / weight-gradient / f16 launches keep their own rule
+        else return J % 128 == 0 ? T_PP256x128 : (J % 64 == 0 ? T_PP256x64 : T_128x64);
+    }
     if (forced >= 0) return (J < 64 || (TILE_BN[forced] == 128 && J < 128)) ? T_64x64 : forced;
     const int64_t cus = num_cus();
     auto tiles = [&](int bm, int bn) { return cdiv64(I, bm) * cdiv64(J, bn) * z; };
@@ -747,7 +841,7 @@ int choose_tile(int64_t I, int64_t J, int64_t z) {
     return T_64x64;
 }
 
-template <int BM, int BN, int WM, int WN, int NS, class LA, class LB, bool XX, bool F16, int OCC = default_occ(BM, BN, WM, WN, NS)>
+template <int BM, int BN, int WM, int WN, int NS, class LA, class LB, bool XX, bool F16, bool PP = false, int OCC = default_occ(BM, BN, WM, WN, NS)>
 int launch_cfg(const typename LA::Op& a, const typename LB::Op& b, GemmParams g, int zdim, hipStream_t st, int kind) {
     g.tiles_i = (int)cdiv64(g.I, BM);
     g.tiles_j = (int)cdiv64(g.J, BN);
@@ -762,19 +856,19 @@ int launch_cfg(const typename LA::Op& a, const typename LB::Op& b, GemmParams g,
     const bool prof = g_prof_on;
     if (prof) prof_begin(st, 2.0 * (double)g.I * (double)g.J * (double)g.R, g.I, g.J, g.R, zdim, BM, BN * 10 + NS,
                          (F16 ? AR_P16_F16 : AR_P16_BF16) * 10000 + kind);
-    if constexpr (!XX && std::is_same_v<LA, RRDense>) {
+    if constexpr (!PP && !XX && std::is_same_v<LA, RRDense>) {
         // persistent: as many workgroups as stay resident (a multiple of 8: one XCD per workgroup for all its tiles)
         static int resident = 0;
         if (resident == 0) {
             int occ = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, sgemm_kernel<BM, BN, WM, WN, NS, LA, LB, XX, F16, OCC>, WM * WN * 64, 0) != hipSuccess || occ < 1) occ = 1;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, sgemm_kernel<BM, BN, WM, WN, NS, LA, LB, XX, F16, PP, OCC>, WM * WN * 64, 0) != hipSuccess || occ < 1) occ = 1;
             resident = occ * num_cus() / 8 * 8;
             if (resident < 8) resident = 8;
         }
         BDETR_CHECK_ARG(zdim == 1 && g.splitk == 1, "sgemm: the persistent kernels take no split-K / batch dimension");
         if ((int)grid.x > resident) grid.x = resident;
     }
-    hipLaunchKernelGGL((sgemm_kernel<BM, BN, WM, WN, NS, LA, LB, XX, F16, OCC>), grid, dim3(WM * WN * 64), 0, st, a, b, g);
+    hipLaunchKernelGGL((sgemm_kernel<BM, BN, WM, WN, NS, LA, LB, XX, F16, PP, OCC>), grid, dim3(WM * WN * 64), 0, st, a, b, g);
     if (prof) prof_end(st);
     return bdetr_launch_status("sgemm");
 }
@@ -784,6 +878,13 @@ int launch_any(const typename LA::Op& a, const typename LB::Op& b, const GemmPar
     switch (tile) {
         case T_128x128:    return launch_cfg<128, 128, 2, 2, 2, LA, LB, XX, F16>(a, b, g, zdim, st, kind);
         case T_128x64:     return launch_cfg<128, 64, 2, 2, 2, LA, LB, XX, F16>(a, b, g, zdim, st, kind);
+        case T_PP256x128:
+            // (the f16 flavour keeps two accumulator sets: with the fragments of a whole K-step resident it does not fit 256 VGPRs)
+            if constexpr (std::is_same_v<LA, RRPatch> && !F16) return launch_cfg<256, 128, 4, 2, 3, LA, LB, XX, F16, true>(a, b, g, zdim, st, kind);
+            else return launch_cfg<128, 128, 2, 2, 2, LA, LB, XX, F16>(a, b, g, zdim, st, kind);
+        case T_PP256x64:
+            if constexpr (std::is_same_v<LA, RRPatch> && !F16) return launch_cfg<256, 64, 4, 2, 3, LA, LB, XX, F16, true>(a, b, g, zdim, st, kind);
+            else return launch_cfg<128, 64, 2, 2, 2, LA, LB, XX, F16>(a, b, g, zdim, st, kind);
         default:           return launch_cfg<64, 64, 2, 2, 2, LA, LB, XX, F16>(a, b, g, zdim, st, kind);
     }
 }
@@ -843,7 +944,7 @@ extern "C" int bdetr_p16_supported(const bdetr_conv_desc* d) {
     return 1;
 }
 
-static int fwd_tile(const bdetr_conv_desc* d) { return choose_tile((int64_t)d->N * d->OH * d->OW, d->K, 1); }
+static int fwd_tile(const bdetr_conv_desc* d) { return choose_tile((int64_t)d->N * d->OH * d->OW, d->K, 1, false); }
 
 extern "C" int bdetr_p16_conv2d_fwd_stat_chunks(const bdetr_conv_desc* d) {
     if (check_conv(d, "bdetr_p16_conv2d_fwd_stat_chunks")) return -1;
@@ -874,7 +975,7 @@ extern "C" int bdetr_p16_conv2d_fwd(const void* x_f16, const void* w_f16, const 
 
 static int bwd_data_tile(const bdetr_conv_desc* d) {
     const bool dense = d->R == 1 && d->S == 1 && d->pad == 0;
-    return choose_tile(dense ? (int64_t)d->N * d->OH * d->OW : (int64_t)d->N * d->H * d->W, d->C, 1);
+    return choose_tile(dense ? (int64_t)d->N * d->OH * d->OW : (int64_t)d->N * d->H * d->W, d->C, 1, !dense);
 }
 
 // number of partial rows bdetr_p16_conv2d_bwd_data writes per statistic when the BatchNorm-backward reduction is fused

@@ -656,9 +656,15 @@ class Model(Layer):
         step that left the fp16 range; that batch and the later ones ran without an update (the optimizer skips while the
         flag is up), so all of them are redone on the exact-fp32 forward and the counters are rolled back for the
         update-free attempts.  force: resolve every outstanding snapshot now (fit() reads the logs on the host anyway)."""
-        snap = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        # (a small ring of pinned words and events, reused: a pinned allocation per step costs more than the step's whole guard)
+        n = self.GUARD_LAG + 2                    # at most GUARD_LAG + 1 snapshots are pending at any time
+        ring = self.__dict__.get("_guard_ring")
+        if ring is None:
+            ring = self._guard_ring = [(torch.empty(1, dtype=torch.int32, pin_memory=True), torch.cuda.Event()) for _ in range(n)]
+            self._guard_slot = -1
+        self._guard_slot = (self._guard_slot + 1) % n
+        snap, ev = ring[self._guard_slot]
         snap.copy_(K.overflow_flag(), non_blocking=True)
-        ev = torch.cuda.Event()
         ev.record()
         self._guard_pending.append((data, snap, ev))
         return self._guard_resolve(logs, 0 if force else self.GUARD_LAG)

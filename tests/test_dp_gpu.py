@@ -154,7 +154,7 @@ batch = {"image": to_device(host["image"]), "category": to_device(host["category
          "bbox": to_device(host["bbox"]), "num_objects": to_device(host["num_objects"], torch.int32)}
 def run(distributed):
     m = small_model()
-    m.compile(optimizer=SGD(1e-2, momentum=.9, nesterov=True, clipnorm=.1))
+    m.compile(optimizer=SGD(1e-3, momentum=.9, nesterov=True, clipnorm=.1))
     if distributed:
         m.distribute()
         assert m._dp.active and m._dp.world == 1 and m.loss_fn.loss_scale == 1.0
@@ -166,20 +166,39 @@ ref, want = run(False)
 m, got = run(True)
 dp = m._dp
 assert dp._comm_stream is not None and dp._expected is not None and len(dp._bounds) >= 3, (dp._comm_stream, len(dp._bounds))
-# freeze -> step -> unfreeze -> step with early launches armed (the advisor's scenario): the optimizer is rebuilt before the
-# step is armed, no bucket is reduced twice, nothing raises
-m.EncoderBackbone.trainable = False; ref.EncoderBackbone.trainable = False
-for _ in range(3):
-    got.append(m.logs_to_host(m.train_step(batch))["loss"]); want.append(ref.logs_to_host(ref.train_step(batch))["loss"])
-m.EncoderBackbone.trainable = True; ref.EncoderBackbone.trainable = True
-for _ in range(3):
-    got.append(m.logs_to_host(m.train_step(batch))["loss"]); want.append(ref.logs_to_host(ref.train_step(batch))["loss"])
-torch.cuda.synchronize()
-# a one-rank all-reduce is the identity: the distributed run tracks the plain one (float atomics of the split-K weight
-# gradients make any two runs differ in the last bits; a 2-image toy amplifies that along the trajectory)
+# a one-rank all-reduce is the identity: the first steps of the distributed run equal the plain one's (later ones drift apart
+# like any two runs do: float atomics of the split-K weight gradients + a chaotic 2-image toy trajectory)
 assert all(np.isfinite(got)), got
-assert all(abs(a - b) <= 2e-3 * abs(b) for a, b in zip(got[:4], want[:4])), (got, want)
-assert all(abs(a - b) <= 5e-2 * abs(b) for a, b in zip(got, want)), (got, want)
+assert abs(got[0] - want[0]) <= 1e-6 * abs(want[0]) and abs(got[1] - want[1]) <= 1e-4 * abs(want[1]), (got, want)
+# freeze -> steps -> unfreeze -> steps with early launches armed (the advisor's scenario): the optimizer is rebuilt before the
+# step is armed, no bucket is reduced twice (a double reduction would double the update), nothing raises
+bb = [v for v in m.EncoderBackbone.variables if v.trainable][:5]
+head = m.CategoryPredictionHead.DenseOut.kernel
+m.EncoderBackbone.trainable = False
+w_bb, w_head = [v.value.clone() for v in bb], head.value.clone()
+for _ in range(3):
+    got.append(m.logs_to_host(m.train_step(batch))["loss"])
+torch.cuda.synchronize()
+assert all(torch.equal(v.value, w) for v, w in zip(bb, w_bb)) and not torch.equal(head.value, w_head)
+n_frozen = len(m.optimizer.vars)
+m.EncoderBackbone.trainable = True
+for _ in range(3):
+    got.append(m.logs_to_host(m.train_step(batch))["loss"])
+torch.cuda.synchronize()
+assert len(m.optimizer.vars) > n_frozen and not all(torch.equal(v.value, w) for v, w in zip(bb, w_bb))
+assert all(np.isfinite(got)), got
+# one more step from identical weights on both models: the all-reduced update equals the plain update
+ref.EncoderBackbone.trainable = True
+ref.set_weights_dict(m.get_weights_dict())
+for x in (m, ref):
+    x.compile(optimizer=SGD(1e-3, momentum=.9, nesterov=True, clipnorm=.1))
+for _ in range(3):                               # builds the flat buffers, calibrates the bucket table, then launches buckets early
+    m.train_step(batch); ref.train_step(batch)
+torch.cuda.synchronize()
+a, b = m.get_weights_dict(), ref.get_weights_dict()
+errs = sorted(((float(np.abs(a[k] - b[k]).max() / (np.abs(b[k]).max() + 1e-12)), k) for k in a), reverse=True)
+worst = errs[0][0]
+assert worst <= 1e-4, errs[:6]
 dp.profile = True
 for _ in range(2):
     m.train_step(batch)

@@ -36,9 +36,10 @@ def test_config2_batch2_matches_oracle(cuda):
     y = model.forward_backward(batch)
     torch.cuda.synchronize()
     out, grads = O.train_step_grads(cfg, params, batch, dtype=torch.float32)
+    out64, g64 = O.train_step_grads(cfg, params, batch, dtype=torch.float64)
     cat = y[0].cpu().numpy()
-    # probabilities, boxes and the three heads' pre-activation logits: every element within 1e-3 (tests/_close.py)
-    check_predictions((model.CategoryPredictionHead, model.AttributePredictionHead, model.BoxPredictionHead), y, out)
+    # probabilities, boxes and the three heads' pre-activation logits: every element within 1e-3 of the fp64 oracle (tests/_close.py)
+    check_predictions((model.CategoryPredictionHead, model.AttributePredictionHead, model.BoxPredictionHead), y, out64)
     assert np.array_equal(cat.argmax(-1), out.cat_preds.detach().numpy().argmax(-1))       # class ids bit-exact
     match = model.loss_fn.last_match.cpu().numpy()
     want = -np.ones_like(match)
@@ -57,7 +58,7 @@ def test_config2_batch2_matches_oracle(cuda):
         assert cos > 0.995, (name, cos)
     # every trainable tensor against the fp64 oracle (relative L2, next to the fp32 oracle's own error)
     from test_model_gpu import check_grads
-    check_grads(model, cfg, params, batch)
+    check_grads(model, cfg, params, batch, g32=grads, g64=g64)
 
 
 def test_config2_batch16_properties(cuda):
@@ -110,13 +111,14 @@ def test_config3_boosted_fashionpedia_batch2_matches_oracle(cuda):
     y = model.forward_backward(batch)
     torch.cuda.synchronize()
     out, grads = O.train_step_grads(cfg, params, batch, dtype=torch.float32)
+    out64, g64 = O.train_step_grads(cfg, params, batch, dtype=torch.float64)
     cat = y[0].cpu().numpy()
-    for name, got, want in zip(("category", "attribute", "box"), y, (out.cat_preds, out.attribute_preds, out.box_preds)):
-        assert_elementwise(got.cpu().numpy(), want.detach().numpy(), name)               # cumulative predictions, every element
+    for name, got, want in zip(("category", "attribute", "box"), y, (out64.cat_preds, out64.attribute_preds, out64.box_preds)):
+        assert_elementwise(got.cpu().numpy(), want.detach().numpy(), name)               # cumulative predictions, every element, vs fp64
     for i in range(3):                                                                   # each weak learner's own logits
         for head, kind in zip((model.CategoryBlocks[i], model.AttributeBlocks[i], model.BoxBlocks[i]), ("Category", "Attribute", "Box")):
             key = f"{kind}PredictionHead_{i}/logits"
-            assert_logits(head.last_logits.cpu().numpy(), out.probes[key].detach().numpy(), key)
+            assert_logits(head.last_logits.cpu().numpy(), out64.probes[key].detach().numpy(), key)
     assert np.array_equal(cat.argmax(-1), out.cat_preds.detach().numpy().argmax(-1))       # class ids bit-exact
     match = model.loss_fn.last_match.cpu().numpy()                                          # last learner's assignment
     want = -np.ones_like(match)
@@ -128,7 +130,7 @@ def test_config3_boosted_fashionpedia_batch2_matches_oracle(cuda):
     assert abs(logs["loss"] - ref) <= 1e-3 * abs(ref)
     # every trainable tensor against the fp64 oracle (relative L2 by grad_report's criterion)
     from test_model_gpu import check_grads
-    check_grads(model, cfg, params, batch)
+    check_grads(model, cfg, params, batch, g32=grads, g64=g64)
 
 
 def test_config5_resnet101_1333x800_300_queries_batch1_matches_oracle(cuda):
@@ -156,7 +158,8 @@ def test_config5_resnet101_1333x800_300_queries_batch1_matches_oracle(cuda):
     y = model.forward_backward(batch)
     torch.cuda.synchronize()
     out, grads = O.train_step_grads(cfg, params, batch, dtype=torch.float32)
-    check_predictions((model.CategoryPredictionHead, model.AttributePredictionHead, model.BoxPredictionHead), y, out)
+    out64, g64 = O.train_step_grads(cfg, params, batch, dtype=torch.float64)
+    check_predictions((model.CategoryPredictionHead, model.AttributePredictionHead, model.BoxPredictionHead), y, out64)
     assert np.array_equal(y[0].cpu().numpy().argmax(-1), out.cat_preds.detach().numpy().argmax(-1))
     match = model.loss_fn.last_match.cpu().numpy()
     want = -np.ones_like(match)
@@ -168,4 +171,4 @@ def test_config5_resnet101_1333x800_300_queries_batch1_matches_oracle(cuda):
     assert abs(logs["loss"] - ref) <= 1e-3 * abs(ref)
     # every trainable tensor against the fp64 oracle (the oracle keeps the scope name "resnet50" for every stage list)
     from test_model_gpu import check_grads
-    check_grads(model, cfg, params, batch, rename=ren)
+    check_grads(model, cfg, params, batch, rename=ren, g32=grads, g64=g64)

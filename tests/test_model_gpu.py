@@ -46,6 +46,7 @@ def run_pair(cfg, batch, boosted=False):
     y_pred = model.forward_backward(batch)
     torch.cuda.synchronize()
     out, grads = O.train_step_grads(cfg, params, batch)
+    out.f64 = O.train_step_grads(cfg, params, batch, dtype=torch.float64)      # (StepOut, grads) in fp64: the target of the element-wise float checks
     return model, y_pred, out, grads, params
 
 
@@ -61,7 +62,8 @@ def test_forward_outputs(config1):
     cfg, batch, model, y_pred, out, grads, params = config1
     cat = y_pred[0].cpu().numpy()
     # every probability, box coordinate and pre-activation logit within 1e-3 of the oracle's, element by element
-    rep = check_predictions(heads_of(model), y_pred, out)
+    # (against the fp64 oracle: on ill-conditioned small configs the CPU fp32 oracle is itself up to 2.5e-3 off element-wise)
+    rep = check_predictions(heads_of(model), y_pred, out.f64[0])
     print({k: (f"{v['max_abs_err']:.2e}", f"{v['max_rel_err_above_atol']:.2e}") for k, v in rep.items()})
     # integer class ids: bit-exact
     ids = cat.argmax(-1)
@@ -132,11 +134,14 @@ def grad_report(model, g32, g64):
     return sorted(rows, reverse=True)
 
 
-def check_grads(model, cfg, params, batch, rename=None):
-    """rename: oracle parameter name -> model variable name (the ResNet-101 scope)."""
+def check_grads(model, cfg, params, batch, rename=None, g32=None, g64=None):
+    """rename: oracle parameter name -> model variable name (the ResNet-101 scope).  g32 / g64: the oracle's gradients when the
+    caller has them already."""
     from oracle import detr_oracle as O
-    _, g32 = O.train_step_grads(cfg, params, batch, dtype=torch.float32)
-    _, g64 = O.train_step_grads(cfg, params, batch, dtype=torch.float64)
+    if g32 is None:
+        _, g32 = O.train_step_grads(cfg, params, batch, dtype=torch.float32)
+    if g64 is None:
+        _, g64 = O.train_step_grads(cfg, params, batch, dtype=torch.float64)
     if rename is not None:
         g32, g64 = {rename(k): v for k, v in g32.items()}, {rename(k): v for k, v in g64.items()}
     rows = grad_report(model, g32, g64)
@@ -149,7 +154,7 @@ def test_gradients(config1):
     cfg, batch, model, y_pred, out, grads, params = config1
     model.set_weights_dict(params)
     model.forward_backward(batch)
-    check_grads(model, cfg, params, batch)
+    check_grads(model, cfg, params, batch, g32=grads, g64=out.f64[1])
 
 
 def test_boosted_three_learners(cuda):
@@ -157,17 +162,18 @@ def test_boosted_three_learners(cuda):
     cfg = O.Config(num_decoder_blocks=3, boosted=True)
     batch = O.make_batch(cfg, 2, 20, seed=77, num_objects=[5, 2])
     model, y_pred, out, grads, params = run_pair(cfg, batch, boosted=True)
-    for name, got, want in zip(("category", "attribute", "box"), y_pred, (out.cat_preds, out.attribute_preds, out.box_preds)):
+    o64 = out.f64[0]
+    for name, got, want in zip(("category", "attribute", "box"), y_pred, (o64.cat_preds, o64.attribute_preds, o64.box_preds)):
         assert_elementwise(got.cpu().numpy(), want.detach().numpy(), name)           # cumulative predictions of the 3 learners
     for i in range(3):                                                               # every learner's own logits
         for head, kind in zip(heads_of(model, i), ("Category", "Attribute", "Box")):
             key = f"{kind}PredictionHead_{i}/logits"
-            assert_logits(head.last_logits.cpu().numpy(), out.probes[key].detach().numpy(), key)
+            assert_logits(head.last_logits.cpu().numpy(), o64.probes[key].detach().numpy(), key)
     logs = model.logs_to_host(model.step_logs())
     assert abs(logs["loss"] - float(out.loss_vector.detach().mean())) <= 1e-3 * abs(float(out.loss_vector.detach().mean()))
     model.set_weights_dict(params)
     model.forward_backward(batch)
-    check_grads(model, cfg, params, batch)
+    check_grads(model, cfg, params, batch, g32=grads, g64=out.f64[1])
 
 
 def test_inference_decode(config1):
@@ -277,8 +283,10 @@ def test_resnet101_backbone_matches_oracle(cuda):
     y = model.forward_backward(batch)
     torch.cuda.synchronize()
     out, g32 = O.train_step_grads(cfg, params, batch, dtype=torch.float32)
-    _, g64 = O.train_step_grads(cfg, params, batch, dtype=torch.float64)
-    check_predictions(heads_of(model), y, out)
+    out64, g64 = O.train_step_grads(cfg, params, batch, dtype=torch.float64)
+    # element-wise against the fp64 oracle: at 128x128 (a 4x4 final map, batch statistics over 32 samples) the CPU fp32 oracle
+    # itself is 2.5e-3 off in single probabilities (measured: element (0,3,3) fp64 0.222270, CPU-fp32 0.222746, this path 0.222352)
+    check_predictions(heads_of(model), y, out64)
     assert np.array_equal(y[0].cpu().numpy().argmax(-1), out.cat_preds.detach().numpy().argmax(-1))
     match = model.loss_fn.last_match.cpu().numpy()
     want = -np.ones_like(match)
