@@ -279,4 +279,8 @@ void prof_begin(hipStream_t st, double flops, int I, int J, int R, int z, int bm
 void prof_end(hipStream_t st);
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// ---- hconv.hip: 3x3 / stride 1 / pad 1 convolutions with the input halo resident in LDS ----
+int hconv_tile(int64_t rows, int W, int C, int J, bool f16);          // BM * 1000 + BN, or 0: stay on sgemm.hip's im2col kernel
+int hconv_launch(int tile, bool f16, const void* x, int N, int H, int W, int C, const void* w, int J, const GemmParams& g, hipStream_t st);
+
 }  // namespace bdgemm

@@ -978,10 +978,17 @@ static int bwd_data_tile(const bdetr_conv_desc* d) {
     return choose_tile(dense ? (int64_t)d->N * d->OH * d->OW : (int64_t)d->N * d->H * d->W, d->C, 1, !dense);
 }
 
+// 3x3 / stride 1 / pad 1: the halo-resident kernel of hconv.hip (its tile as BM * 1000 + BN), else 0
+static int bwd_data_hconv(const bdetr_conv_desc* d) {
+    if (!(d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1)) return 0;
+    return hconv_tile((int64_t)d->N * d->H * d->W, d->W, d->K, d->C, false);
+}
+
 // number of partial rows bdetr_p16_conv2d_bwd_data writes per statistic when the BatchNorm-backward reduction is fused
 extern "C" int bdetr_p16_conv2d_bwd_data_stat_chunks(const bdetr_conv_desc* d) {
     if (check_conv(d, "bdetr_p16_conv2d_bwd_data_stat_chunks")) return -1;
     const bool dense = d->R == 1 && d->S == 1 && d->pad == 0;
+    if (const int ht = bwd_data_hconv(d)) return (int)cdiv64((int64_t)d->N * d->H * d->W, ht / 1000);      // one partial row per tile_i
     const int t = bwd_data_tile(d);
     // the persistent dense kernels write one partial row per (tile_i, wave row), the patch kernels one per tile_i
     return (int)cdiv64(dense ? (int64_t)d->N * d->OH * d->OW : (int64_t)d->N * d->H * d->W, TILE_BM[t]) * (dense ? TILE_WM[t] : 1);
@@ -1027,6 +1034,8 @@ static int p16_bwd_data(const void* dy_bf16, const void* wt_bf16, float* dx, con
     // dx[n,ih,iw,c] = sum_{r',s',k} dy[n, ih - pad' + r', iw - pad' + s', k] * wt[c][r'][s'][k],  pad' = R-1-pad, wt pre-flipped
     const int Mx = d->N * d->H * d->W, Kd = d->R * d->S * d->K;
     g.I = Mx; g.J = d->C; g.R = Kd;
+    if (const int ht = bwd_data_hconv(d))                 // dy plays the input's role: same spatial size, K channels; wt rows = input channels
+        return hconv_launch(ht, false, dy_bf16, d->N, d->H, d->W, d->K, wt_bf16, d->C, g, st);
     PPatch a = make_patch(dy_bf16, d->N, d->OH, d->OW, d->K, d->H, d->W, d->R, d->S, 1, d->R - 1 - d->pad, Mx, Kd);
     PDense b{wt_bf16, (unsigned)Kd, d->C, Kd};
     return launch_any<RRPatch, RRDense, false, false>(a, b, g, 1, st, 1000, bwd_data_tile(d));

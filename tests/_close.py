@@ -39,13 +39,34 @@ def assert_logits(got, want, what=""):
     return assert_elementwise(got, want, what, RTOL, logit_atol(want))
 
 
-def check_predictions(model_heads, y_pred, out, suffix="", probes=None):
-    """Probabilities, boxes (element-wise 1e-3 + 1e-6) and the three heads' pre-activation logits against the oracle's StepOut.
-    model_heads = (category head, attribute head, box head) whose `last_logits` the step just produced."""
+def _fp32_oracle_rel(want32, want64, atol) -> float:
+    """Worst element-wise error of the CPU fp32 oracle against the fp64 one, as a relative tolerance (0 when it meets 1e-3)."""
+    w32, w64 = np.asarray(want32, np.float64), np.asarray(want64, np.float64)
+    need = (np.abs(w32 - w64) - atol) / np.maximum(np.abs(w64), 1e-300)
+    return float(max(need.max(), 0.0))
+
+
+def check_predictions(model_heads, y_pred, out, suffix="", probes=None, out32=None):
+    """Probabilities, boxes (element-wise 1e-3 + 1e-6) and the three heads' pre-activation logits against the oracle's StepOut
+    (`out`: the fp64 run).  model_heads = (category head, attribute head, box head) whose `last_logits` the step just produced.
+
+    out32 (optional): the CPU fp32 oracle's StepOut for an ILL-CONDITIONED config (batch statistics over a few dozen samples):
+    there the reference's own fp32 arithmetic misses 1e-3 element-wise against fp64, and the bound becomes "1e-3, or as close to
+    the exact result as the fp32 reference itself gets" (rtol = max(1e-3, the fp32 oracle's worst element); both printed)."""
     reports = {}
-    for name, got, want in zip(("category", "attribute", "box"), y_pred, (out.cat_preds, out.attribute_preds, out.box_preds)):
-        reports[name] = assert_elementwise(got.detach().cpu().numpy(), want.detach().numpy(), name)
+    for name, got, attr in zip(("category", "attribute", "box"), y_pred, ("cat_preds", "attribute_preds", "box_preds")):
+        want = getattr(out, attr).detach().numpy()
+        rtol = RTOL
+        if out32 is not None:
+            rtol = max(RTOL, _fp32_oracle_rel(getattr(out32, attr).detach().numpy(), want, ATOL_PROB))
+        reports[name] = assert_elementwise(got.detach().cpu().numpy(), want, name, rtol)
+        reports[name]["rtol_used"] = rtol
     probes = out.probes if probes is None else probes
     for head, key in zip(model_heads, (f"CategoryPredictionHead{suffix}/logits", f"AttributePredictionHead{suffix}/logits", f"BoxPredictionHead{suffix}/logits")):
-        reports[key] = assert_logits(head.last_logits.detach().cpu().numpy(), probes[key].detach().numpy(), key)
+        want = probes[key].detach().numpy()
+        atol, rtol = logit_atol(want), RTOL
+        if out32 is not None:
+            rtol = max(RTOL, _fp32_oracle_rel(out32.probes[key].detach().numpy(), want, atol))
+        reports[key] = assert_elementwise(head.last_logits.detach().cpu().numpy(), want, key, rtol, atol)
+        reports[key]["rtol_used"] = rtol
     return reports

@@ -187,25 +187,33 @@ for _ in range(3):
 torch.cuda.synchronize()
 assert len(m.optimizer.vars) > n_frozen and not all(torch.equal(v.value, w) for v, w in zip(bb, w_bb))
 assert all(np.isfinite(got)), got
-# one more step from identical weights on both models: the all-reduced update equals the plain update
+# From identical weights, one gradient on each model: the distributed one with early bucket launches armed (its bucket table is
+# calibrated, the flat buffer unchanged), the plain one without.  A one-rank all-reduce is the identity, so the two gradients
+# agree to the noise of the split-K float atomics - a bucket reduced twice, torn or launched before its last contribution would not.
+# (Weights after several steps are NOT comparable on this 2-image toy: BatchNorm over 8 samples amplifies last-bit noise to
+# percents within three steps - measured.)
 ref.EncoderBackbone.trainable = True
+for _ in range(2):
+    ref.train_step(batch)                         # builds ref's flat buffer for the same trainable set
 ref.set_weights_dict(m.get_weights_dict())
-for x in (m, ref):
-    x.compile(optimizer=SGD(1e-3, momentum=.9, nesterov=True, clipnorm=.1))
-for _ in range(3):                               # builds the flat buffers, calibrates the bucket table, then launches buckets early
-    m.train_step(batch); ref.train_step(batch)
+assert dp._expected is not None
+m.forward_backward(batch); m.optimizer.stage_gradients(m.trainable_variables); dp.finish(m.optimizer.flat_grad)
+assert any(dp._launched) and dp._expected is not None     # buckets went out from the backward pass, not from finish()
+ref.forward_backward(batch); ref.optimizer.stage_gradients(ref.trainable_variables)
 torch.cuda.synchronize()
-a, b = m.get_weights_dict(), ref.get_weights_dict()
-errs = sorted(((float(np.abs(a[k] - b[k]).max() / (np.abs(b[k]).max() + 1e-12)), k) for k in a), reverse=True)
+gm = {v.name: v.grad.double() for v in m.trainable_variables}
+gr = {v.name: v.grad.double() for v in ref.trainable_variables}
+gmax = max(float(g.abs().max()) for g in gr.values())
+errs = sorted(((float((gm[k] - gr[k]).norm() / gr[k].norm()), k) for k in gr if float(gr[k].abs().max()) > 1e-6 * gmax), reverse=True)
 worst = errs[0][0]
-assert worst <= 1e-4, errs[:6]
+assert len(errs) > 100 and worst <= 2e-4, errs[:6]
 dp.profile = True
 for _ in range(2):
     m.train_step(batch)
 summary = dp.profile_summary()
 assert summary is not None and summary["buckets_per_step"] >= 3 and summary["allreduce_ms_per_step"] > 0, summary
 flag = torch.zeros(1, dtype=torch.int32, device="cuda"); dp.any_(flag); dp.broadcast_variables(m.variables[:3]); dp.barrier()
-print("RCCL_ONE_RANK_OK rccl", ".".join(str(x) for x in torch.cuda.nccl.version()), "buckets", len(dp._bounds), summary)
+print("RCCL_ONE_RANK_OK worst_grad_rel_l2 %.2e rccl" % worst, ".".join(str(x) for x in torch.cuda.nccl.version()), "buckets", len(dp._bounds), summary)
 dist.destroy_process_group()
 '''
 
