@@ -137,7 +137,7 @@ def hbm_traffic_per_launch():
 ENV_REFUSED = ("BDETR_SGEMM_DBG",)
 ENV_RECORDED = ("BDETR_STILE", "BDETR_TILE", "BDETR_P16", "BDETR_BN_FUSE", "BDETR_LAZY_SKIP", "BDETR_WGRAD_WANT", "BDETR_WGRAD_MINSTAGES",
                 "BDETR_GEMM_PRECISION", "BDETR_SIDE_STREAM", "BDETR_SIDE_PRIORITY", "BDETR_GRAPH", "BDETR_DP_OVERLAP", "BDETR_DP_FORCE", "BDETR_LIB",
-                "BDETR_CXXFLAGS", "BDETR_FORCE_DEVICE", "BDETR_DIST_BACKEND", "BDETR_CPU_THREADS", "BDETR_HCONV")
+                "BDETR_CXXFLAGS", "BDETR_FORCE_DEVICE", "BDETR_DIST_BACKEND", "BDETR_CPU_THREADS", "BDETR_HCONV", "BDETR_ATTN_SPLIT")
 
 
 def env_overrides() -> dict:
@@ -167,8 +167,8 @@ def roofline_by_class(L, steps):
         if ms <= 0:
             continue
         arith, lk = kind // 10000, kind % 10000
-        if arith >= 3:                           # sgemm.hip: 0 dense, 1000 patch rows, 2000 dense wgrad, 3000 patch-column wgrad
-            a_patch, b_patch = lk == 1000, lk == 3000
+        if arith >= 3:                           # sgemm.hip: 0 dense, 1000 patch rows, 2000 dense wgrad, 3000 patch-column wgrad; hconv.hip: 4000 (halo-resident 3x3)
+            a_patch, b_patch = lk in (1000, 4000), lk == 3000
         else:                                    # igemm.hip: LoaderId<LA> * 1000 + A_RC * 100 + LoaderId<LB> * 10 + B_RC, patch loader id 1
             a_patch, b_patch = lk // 1000 == 1, lk // 10 % 10 == 1
         patch = a_patch or b_patch

@@ -1,4 +1,4 @@
-// attention.hip - fused multi-head attention core for gfx950 (head dim 32, exact fp32 MFMA).
+// attention.hip - fused multi-head attention core for gfx950 (head dim 32; exact fp32 MFMA or three split 16-bit MFMA products).
 //
 // Replaces transformers.py:86-97 (MatMulQueryKey -> Rescaling(1/sqrt(d)) -> softmax -> mask of ones
 // -> MatMulQueryValue) and its autodiff.  The [B,h,q,k] score tensor is never written to HBM:
@@ -12,12 +12,30 @@
 // already the B operand of O^T += V^T P^T - P never touches LDS.  The backward uses the same layout
 // twice: once with queries on the columns (dQ) and once with keys on the columns (dK, dV).
 //
+// Arithmetic (AR, chosen per launch from the library's GEMM policy, include/bdetr.h): 0 = exact fp32 (v_mfma_f32_32x32x2_f32,
+// 64 cycles per 32x32x2: a 32-deep tile product costs 1,024 cycles); 2 = split-f16 forward / 1 = split-bf16 gradients - the
+// streamed chunk is split into hi + lo 16-bit halves ONCE when it is written to LDS, the column operand once per kernel, an
+// accumulator tile right before it is consumed, and a tile product is 2 x 3 v_mfma_f32_32x32x16 (192 cycles).  Same split
+// arithmetic as the convolutions (csrc/p16.h: hi = half(x), lo = half(x - hi), one accumulator).  Measured round 3: the fp32
+// kernels were MFMA-bound at ~50 % of the fp32 MFMA peak.
+//
 // Layouts: q/k/v/dq/dk/dv are [B, n, h*32] (head h at columns 32h..32h+31, exactly what the Dense
 // projections produce); o/do are [B, h, q, 32] (the layout the reference reshapes without a
 // permute, transformers.py:100); lse/dvec are [B, h, q].
 #include "common.h"
+#include "p16.h"
+#include <stdlib.h>
+
+namespace bdgemm { int gemm_mode(); }      // igemm.hip: the library's arithmetic policy (BDETR_GEMM_*)
 
 namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 abf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 af16x8 __attribute__((ext_vector_type(8)));
+enum { AR_FP32 = 0, AR_BF16 = 1, AR_F16 = 2 };
 
 constexpr int AD = 32;            // head dimension
 constexpr int ALD = AD + 4;       // LDS row stride (floats): conflict-free 16-byte row reads
@@ -83,18 +101,133 @@ __device__ __forceinline__ void accumulate_rt_tile(f32x16& acc, const float* __r
     }
 }
 
+// ---------------- split (16-bit pair) flavour of the two tile products ----------------
+// LDS image of a streamed 64 x 32 chunk: two planes (hi at +0, lo at +IMG_PLANE) of [64 rows][32 d] 16-bit = 64 bytes per row;
+// the four 16-byte chunks of row r are XOR-ed with (r >> 2) & 3.  Row reads (ds_read_b128: lane = row) are then conflict-free -
+// the 16 lanes of a read group see 4 distinct (r & 3) x 4 distinct chunks -, and so are the transposing reads
+// (ds_read_b64_tr_b16: a half-wave reads 4 whole rows = 256 contiguous bytes, whatever the permutation inside a row).
+constexpr int IMG_PLANE = CH * 64, IMG_BYTES = 2 * IMG_PLANE;
+constexpr int SMEM_BYTES = IMG_BYTES > CH * ALD * 4 ? IMG_BYTES : CH * ALD * 4;
+
+template <int AR>
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigned& lo) {
+    if (AR == AR_F16) p16_split2_f16(x0, x1, hi, lo); else p16_split2_bf16(x0, x1, hi, lo);
+}
+template <int AR>
+__device__ __forceinline__ f32x16 mfma3(const u32x4& ah, const u32x4& al, const u32x4& bh, const u32x4& bl, f32x16 acc) {
+    if (AR == AR_F16) {
+#define H8(v) __builtin_bit_cast(af16x8, v)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(al), H8(bh), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(ah), H8(bl), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(ah), H8(bh), acc, 0, 0, 0);
+#undef H8
+    } else {
+#define B8(v) __builtin_bit_cast(abf16x8, v)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B8(al), B8(bh), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B8(ah), B8(bl), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(B8(ah), B8(bh), acc, 0, 0, 0);
+#undef B8
+    }
+    return acc;
+}
+template <int AR>
+__device__ __forceinline__ void store_chunk_split(unsigned char* __restrict__ img, const ChunkRegs& c) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int v = threadIdx.x + 256 * p, row = v >> 3, c4 = v & 7;
+        unsigned h0, l0, h1, l1;
+        split2<AR>(c.v[p][0], c.v[p][1], h0, l0);
+        split2<AR>(c.v[p][2], c.v[p][3], h1, l1);
+        const int off = row * 64 + (((c4 >> 1) ^ ((row >> 2) & 3)) << 4) + ((c4 & 1) << 3);
+        *reinterpret_cast<u32x2*>(img + off) = u32x2{h0, h1};
+        *reinterpret_cast<u32x2*>(img + IMG_PLANE + off) = u32x2{l0, l1};
+    }
+}
+// a lane's 16 column values creg[s] = C[j][16 lh + s] -> the B fragments of the two 16-deep MFMA steps: step s2, element e <-> d = 16 lh + 8 s2 + e
+struct ColFrag { u32x4 h[2], l[2]; };
+template <int AR>
+__device__ __forceinline__ ColFrag col_frag(const float (&r)[16]) {
+    ColFrag f;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { unsigned h, l; split2<AR>(r[8 * s2 + 2 * e], r[8 * s2 + 2 * e + 1], h, l); f.h[s2][e] = h; f.l[s2][e] = l; }
+    return f;
+}
+// tile[i][j] = sum_d R[32t+i][d] * C[j][d]: A fragment of step s2 = the 16 bytes of row 32t + li at d = 16 lh + 8 s2 (one ds_read_b128 per plane)
+template <int AR>
+__device__ __forceinline__ f32x16 row_times_col_split(const unsigned char* __restrict__ img, int t, const ColFrag& c, int li, int lh) {
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const int row = 32 * t + li;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        const int off = row * 64 + (((2 * lh + s2) ^ ((row >> 2) & 3)) << 4);
+        const u32x4 ah = *reinterpret_cast<const u32x4*>(img + off), al = *reinterpret_cast<const u32x4*>(img + IMG_PLANE + off);
+        acc = mfma3<AR>(ah, al, c.h[s2], c.l[s2], acc);
+    }
+    return acc;
+}
+// acc[d][j] += sum_r R[32t+r][d] * T[r][j], T in accumulator layout.  Step s2 takes T's registers 8 s2 .. 8 s2 + 7 as the B fragment:
+// element e of lane half lh is row 16 s2 + 8 (e >> 2) + 4 lh + (e & 3), so the A fragment (lane = column d of R, transposed) must hold
+// those same rows: two transposing reads per plane, each delivering 4 consecutive rows of the lane's column.
+template <int AR>
+__device__ __forceinline__ void accumulate_rt_tile_split(f32x16& acc, const unsigned char* __restrict__ img, int t, const f32x16& tile, int lane) {
+    const int lh = lane >> 5, g16 = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        u32x4 bh, bl;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { unsigned h, l; split2<AR>(tile[8 * s2 + 2 * e], tile[8 * s2 + 2 * e + 1], h, l); bh[e] = h; bl[e] = l; }
+        u32x2 ah2[2], al2[2];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int row = 32 * t + 16 * s2 + 8 * jj + 4 * lh + q;            // the block's row this lane addresses (columns 16 g16 + 4 p .. + 3)
+            const int off = row * 64 + ((((2 * g16) + (p >> 1)) ^ ((row >> 2) & 3)) << 4) + ((p & 1) << 3);
+            ah2[jj] = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + off)));
+            al2[jj] = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + IMG_PLANE + off)));
+        }
+        const u32x4 ah = {ah2[0][0], ah2[0][1], ah2[1][0], ah2[1][1]}, al = {al2[0][0], al2[0][1], al2[1][0], al2[1][1]};
+        acc = mfma3<AR>(ah, al, bh, bl, acc);
+    }
+}
+
+// one interface over both flavours
+template <int AR> struct ColOperand { float r[16]; ColFrag f; };
+template <int AR>
+__device__ __forceinline__ void chunk_store(unsigned char* smem, const ChunkRegs& c) {
+    if constexpr (AR == AR_FP32) store_chunk(reinterpret_cast<float*>(smem), c); else store_chunk_split<AR>(smem, c);
+}
+template <int AR>
+__device__ __forceinline__ f32x16 rows_x_col(const unsigned char* smem, int t, const ColOperand<AR>& c, int li, int lh) {
+    if constexpr (AR == AR_FP32) return row_times_col(reinterpret_cast<const float*>(smem), t, c.r, li, lh);
+    else return row_times_col_split<AR>(smem, t, c.f, li, lh);
+}
+template <int AR>
+__device__ __forceinline__ void rowsT_x_tile(f32x16& acc, const unsigned char* smem, int t, const f32x16& tile, int lane) {
+    if constexpr (AR == AR_FP32) accumulate_rt_tile(acc, reinterpret_cast<const float*>(smem), t, tile, lane & 31, lane >> 5);
+    else accumulate_rt_tile_split<AR>(acc, smem, t, tile, lane);
+}
+template <int AR>
+__device__ __forceinline__ void col_operand(ColOperand<AR>& c, const float* __restrict__ base, int64_t stride, int col, bool ok, int lh) {
+    load_col_regs(c.r, base, stride, col, ok, lh);
+    if constexpr (AR != AR_FP32) c.f = col_frag<AR>(c.r);
+}
+
+template <int AR>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                                        float* __restrict__ o, float* __restrict__ lse,
                                                        int h, int nq, int nk, float scale) {
-    __shared__ __attribute__((aligned(16))) float sK[CH * ALD];
-    __shared__ __attribute__((aligned(16))) float sV[CH * ALD];
+    __shared__ __attribute__((aligned(16))) unsigned char sK[SMEM_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char sV[SMEM_BYTES];
     const int b = blockIdx.z, head = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
     const int64_t D = (int64_t)h * AD;
     const int qi = blockIdx.x * COLS_PER_BLOCK + wave * 32 + li;
     const bool qok = qi < nq;
-    float qr[16];
-    load_col_regs(qr, q + (int64_t)b * nq * D + head * AD, D, qi, qok, lh);
+    ColOperand<AR> qr;
+    col_operand<AR>(qr, q + (int64_t)b * nq * D + head * AD, D, qi, qok, lh);
     const float* kbase = k + (int64_t)b * nk * D + head * AD;
     const float* vbase = v + (int64_t)b * nk * D + head * AD;
 
@@ -107,8 +240,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     ChunkRegs ck = fetch_chunk(kbase, D, 0, nk), cv = fetch_chunk(vbase, D, 0, nk);
     for (int c0 = 0; c0 < nk; c0 += CH) {
         __syncthreads();
-        store_chunk(sK, ck);
-        store_chunk(sV, cv);
+        chunk_store<AR>(sK, ck);
+        chunk_store<AR>(sV, cv);
         __syncthreads();
         if (c0 + CH < nk) { ck = fetch_chunk(kbase, D, c0 + CH, nk); cv = fetch_chunk(vbase, D, c0 + CH, nk); }
         if (!wave_active) continue;
@@ -116,7 +249,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
         float cmax = -INFINITY;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            s[t] = row_times_col(sK, t, qr, li, lh);               // S^T tile: rows = keys, column = this lane's query
+            s[t] = rows_x_col<AR>(sK, t, qr, li, lh);              // S^T tile: rows = keys, column = this lane's query
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const float val = (c0 + 32 * t + crow(e, lh) < nk) ? s[t][e] * scale : -INFINITY;
@@ -138,7 +271,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
 #pragma unroll
         for (int e = 0; e < 16; ++e) oacc[e] *= alpha;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) accumulate_rt_tile(oacc, sV, t, s[t], li, lh);    // O^T += V^T P^T
+        for (int t = 0; t < 2; ++t) rowsT_x_tile<AR>(oacc, sV, t, s[t], lane);       // O^T += V^T P^T
     }
     if (qok) {
         const float inv = 1.0f / l;
@@ -164,13 +297,13 @@ __global__ __launch_bounds__(256) void attn_dvec_kernel(const float* __restrict_
 
 // KCOL == false: columns = queries, streamed rows = keys     -> out1 = dQ
 // KCOL == true : columns = keys,    streamed rows = queries  -> out1 = dK, out2 = dV
-template <bool KCOL>
+template <bool KCOL, int AR>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                                        const float* __restrict__ d_o, const float* __restrict__ lse, const float* __restrict__ dvec,
                                                        float* __restrict__ out1, float* __restrict__ out2,
                                                        int h, int nq, int nk, float scale) {
-    __shared__ __attribute__((aligned(16))) float sR1[CH * ALD];
-    __shared__ __attribute__((aligned(16))) float sR2[CH * ALD];
+    __shared__ __attribute__((aligned(16))) unsigned char sR1[SMEM_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char sR2[SMEM_BYTES];
     __shared__ float sL[CH], sD[CH];
     const int b = blockIdx.z, head = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
@@ -184,9 +317,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     const float* c1base = (KCOL ? k : q) + (int64_t)b * ncol * D + head * AD;
     const float* c2base = KCOL ? (v + (int64_t)b * nk * D + head * AD) : (d_o + bh * nq * AD);
     const int64_t c2stride = KCOL ? D : AD;
-    float c1r[16], c2r[16];
-    load_col_regs(c1r, c1base, D, ci, cok, lh);
-    load_col_regs(c2r, c2base, c2stride, ci, cok, lh);
+    ColOperand<AR> c1r, c2r;
+    col_operand<AR>(c1r, c1base, D, ci, cok, lh);
+    col_operand<AR>(c2r, c2base, c2stride, ci, cok, lh);
     // streamed row-side operands
     const float* r1base = (KCOL ? q : k) + (int64_t)b * nrow * D + head * AD;
     const float* r2base = KCOL ? (d_o + bh * nq * AD) : (v + (int64_t)b * nk * D + head * AD);
@@ -203,8 +336,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     ChunkRegs c1 = fetch_chunk(r1base, D, 0, nrow), c2 = fetch_chunk(r2base, r2stride, 0, nrow);
     for (int c0 = 0; c0 < nrow; c0 += CH) {
         __syncthreads();
-        store_chunk(sR1, c1);
-        store_chunk(sR2, c2);
+        chunk_store<AR>(sR1, c1);
+        chunk_store<AR>(sR2, c2);
         if (KCOL && threadIdx.x < CH) {
             const int qi = c0 + threadIdx.x;
             sL[threadIdx.x] = qi < nq ? lse[bh * nq + qi] : 0.f;
@@ -215,8 +348,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
         if (!wave_active) continue;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            f32x16 S = row_times_col(sR1, t, c1r, li, lh);      // scores      (rows = streamed side)
-            f32x16 G = row_times_col(sR2, t, c2r, li, lh);      // dP          (same orientation)
+            f32x16 S = rows_x_col<AR>(sR1, t, c1r, li, lh);     // scores      (rows = streamed side)
+            f32x16 G = rows_x_col<AR>(sR2, t, c2r, li, lh);     // dP          (same orientation)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int r = 32 * t + crow(e, lh);
@@ -225,8 +358,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
                 S[e] = p * (G[e] - Dq) * scale;                  // dS (gradient w.r.t. the unscaled product)
                 G[e] = p;
             }
-            accumulate_rt_tile(acc1, sR1, t, S, li, lh);         // dQ^T += K^T dS^T   |  dK^T += Q^T dS
-            if (KCOL) accumulate_rt_tile(acc2, sR2, t, G, li, lh);   // dV^T += dO^T P
+            rowsT_x_tile<AR>(acc1, sR1, t, S, lane);             // dQ^T += K^T dS^T   |  dK^T += Q^T dS
+            if (KCOL) rowsT_x_tile<AR>(acc2, sR2, t, G, lane);   // dV^T += dO^T P
         }
     }
     if (cok) {
@@ -239,6 +372,13 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
             for (int e = 0; e < 16; ++e) o2[crow(e, lh)] = acc2[e];
         }
     }
+}
+
+// BDETR_ATTN_SPLIT=0 keeps every attention product on the exact-fp32 MFMA (A/B measurements; recorded by bench.py when set)
+bool attn_split_enabled() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("BDETR_ATTN_SPLIT"); on = e ? atoi(e) != 0 : 1; }
+    return on != 0;
 }
 
 int check_attn(const void* a, const void* b, const void* c, int B, int h, int nq, int nk, const char* who) {
@@ -257,7 +397,12 @@ extern "C" int bdetr_attention_fwd(const float* q, const float* k, const float* 
     if (int e = check_attn(q, k, v, B, h, nq, nk, "bdetr_attention_fwd")) return e;
     BDETR_CHECK_ARG(o && lse, "bdetr_attention_fwd: null output");
     dim3 grid((nq + COLS_PER_BLOCK - 1) / COLS_PER_BLOCK, h, B);
-    hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, q, k, v, o, lse, h, nq, nk, scale);
+    // forward products follow the policy's forward arithmetic: split-f16 under BDETR_GEMM_SPLIT (operands are LayerNorm-scale
+    // projections and probabilities), split-bf16 under BDETR_GEMM_BF16X3, exact fp32 otherwise
+    const int mode = attn_split_enabled() ? bdgemm::gemm_mode() : BDETR_GEMM_FP32;
+    if (mode == BDETR_GEMM_SPLIT) hipLaunchKernelGGL((attn_fwd_kernel<AR_F16>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, o, lse, h, nq, nk, scale);
+    else if (mode == BDETR_GEMM_BF16X3) hipLaunchKernelGGL((attn_fwd_kernel<AR_BF16>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, o, lse, h, nq, nk, scale);
+    else hipLaunchKernelGGL((attn_fwd_kernel<AR_FP32>), grid, dim3(256), 0, (hipStream_t)stream, q, k, v, o, lse, h, nq, nk, scale);
     return bdetr_launch_status("attention_fwd");
 }
 
@@ -269,9 +414,14 @@ extern "C" int bdetr_attention_bwd(const float* q, const float* k, const float* 
     hipStream_t st = (hipStream_t)stream;
     const int64_t rows = (int64_t)B * h * nq;
     hipLaunchKernelGGL(attn_dvec_kernel, dim3((unsigned)((rows * 8 + 255) / 256)), dim3(256), 0, st, o, d_o, dvec_ws, rows);
-    hipLaunchKernelGGL((attn_bwd_kernel<false>), dim3((nq + COLS_PER_BLOCK - 1) / COLS_PER_BLOCK, h, B), dim3(256), 0, st,
-                       q, k, v, d_o, lse, dvec_ws, dq, (float*)nullptr, h, nq, nk, scale);
-    hipLaunchKernelGGL((attn_bwd_kernel<true>), dim3((nk + COLS_PER_BLOCK - 1) / COLS_PER_BLOCK, h, B), dim3(256), 0, st,
-                       q, k, v, d_o, lse, dvec_ws, dk, dv, h, nq, nk, scale);
+    // gradient products: split-bf16 (fp32 range) under every policy but BDETR_GEMM_FP32, like the conv / GEMM family
+    const dim3 gq((nq + COLS_PER_BLOCK - 1) / COLS_PER_BLOCK, h, B), gk((nk + COLS_PER_BLOCK - 1) / COLS_PER_BLOCK, h, B);
+    if (!attn_split_enabled() || bdgemm::gemm_mode() == BDETR_GEMM_FP32) {
+        hipLaunchKernelGGL((attn_bwd_kernel<false, AR_FP32>), gq, dim3(256), 0, st, q, k, v, d_o, lse, dvec_ws, dq, (float*)nullptr, h, nq, nk, scale);
+        hipLaunchKernelGGL((attn_bwd_kernel<true, AR_FP32>), gk, dim3(256), 0, st, q, k, v, d_o, lse, dvec_ws, dk, dv, h, nq, nk, scale);
+    } else {
+        hipLaunchKernelGGL((attn_bwd_kernel<false, AR_BF16>), gq, dim3(256), 0, st, q, k, v, d_o, lse, dvec_ws, dq, (float*)nullptr, h, nq, nk, scale);
+        hipLaunchKernelGGL((attn_bwd_kernel<true, AR_BF16>), gk, dim3(256), 0, st, q, k, v, d_o, lse, dvec_ws, dk, dv, h, nq, nk, scale);
+    }
     return bdetr_launch_status("attention_bwd");
 }

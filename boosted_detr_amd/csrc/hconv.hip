@@ -130,20 +130,13 @@ void hconv_kernel(HInput xa, HWeight wb, GemmParams g)
     }
 
     // ---------------- accumulators ----------------
-    constexpr int TM2 = F16 ? TM : 1, TN2 = F16 ? TN : 1;
-    f32x16 acc[TM][TN], acc2[TM2][TN2];
+    f32x16 acc[TM][TN];                                   // one set for all three split products, f16 pairs included (p16.h)
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int b = 0; b < TN; ++b)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-#pragma unroll
-    for (int a = 0; a < TM2; ++a)
-#pragma unroll
-        for (int b = 0; b < TN2; ++b)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc2[a][b][e] = 0.f;
 
     // ---------------- fragments ----------------
     u32x4 fah[2][TM], fal[2][TM], fbh[2][TN], fbl[2][TN];
@@ -200,8 +193,8 @@ void hconv_kernel(HInput xa, HWeight wb, GemmParams g)
                 for (int b = 0; b < TN; ++b) {
                     if constexpr (F16) {
 #define H8(v) __builtin_bit_cast(f16x8, v)
-                        acc2[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(fal[ks][a]), H8(fbh[ks][b]), acc2[a][b], 0, 0, 0);
-                        acc2[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(fah[ks][a]), H8(fbl[ks][b]), acc2[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(fal[ks][a]), H8(fbh[ks][b]), acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(fah[ks][a]), H8(fbl[ks][b]), acc[a][b], 0, 0, 0);
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(fah[ks][a]), H8(fbh[ks][b]), acc[a][b], 0, 0, 0);
 #undef H8
                     } else {
@@ -264,14 +257,6 @@ void hconv_kernel(HInput xa, HWeight wb, GemmParams g)
         }
     if (!grpY) asm volatile("s_barrier" ::: "memory");     // X's matching extra barrier (Y is multiplying its last step)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the trailing out-of-range loads target LDS the epilogue is about to reuse
-    if constexpr (F16) {
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int b = 0; b < TN; ++b)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[a][b][e] += acc2[a][b][e] * (1.f / 2048.f);
-    }
     gemm_epilogue<BM, BN, WM, WN, NT, LDS_BYTES / 4>(acc, g, reinterpret_cast<float*>(lds), tile_i, i0, j0, g.c, bias_pre);
 }
 
@@ -296,7 +281,8 @@ namespace bdgemm {
 int hconv_tile(int64_t rows, int W, int C, int J, bool f16) {
     static int enabled = -1;
     if (enabled < 0) { const char* e = getenv("BDETR_HCONV"); enabled = e ? atoi(e) : 1; }
-    if (!enabled || f16) return 0;                         // (the f16 flavour's two accumulator sets do not fit beside a whole K-step of fragments)
+    if (!enabled) return 0;
+    (void)f16;                                             // both flavours: one accumulator set since the f16 pair's lo half is unscaled (p16.h)
     if (C % 32 || J % 64 || rows >= (1LL << 31)) return 0;
     const int bn = J % 128 == 0 ? 128 : 64;
     const int64_t cus = num_cus();
@@ -313,12 +299,11 @@ int hconv_launch(int tile, bool f16, const void* x, int N, int H, int W, int C, 
     HInput xi{x, N, H, W, C, N * H * W};
     HWeight wi{w, (unsigned)(9 * C), J};
     const int kind = 4000;                                  // profiling class: halo-resident 3x3
-    if (f16) return -1;
     switch (tile) {
-        case 256128: return launch<256, 128, false>(xi, wi, g, st, kind);
-        case 128128: return launch<128, 128, false>(xi, wi, g, st, kind);
-        case 256064: return launch<256, 64, false>(xi, wi, g, st, kind);
-        default: return -1;
+        case 256128: return f16 ? launch<256, 128, true>(xi, wi, g, st, kind) : launch<256, 128, false>(xi, wi, g, st, kind);
+        case 128128: return f16 ? launch<128, 128, true>(xi, wi, g, st, kind) : launch<128, 128, false>(xi, wi, g, st, kind);
+        case 256064: return f16 ? launch<256, 64, true>(xi, wi, g, st, kind) : launch<256, 64, false>(xi, wi, g, st, kind);
+        default: bdetr_set_error("hconv_launch: no such tile %d", tile); return -1;
     }
 }
 

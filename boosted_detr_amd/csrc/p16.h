@@ -8,7 +8,13 @@ typedef __bf16 p16_bf16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 p16_f16x2 __attribute__((ext_vector_type(2)));
 typedef float p16_f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr float P16_LO_SCALE = 2048.f;          // the f16 lo half is stored scaled by 2^11 (keeps it out of f16 subnormals)
+// f16 pair: hi = f16(x), lo = f16(x - hi), both UNSCALED, so that the three split products hi*hi + hi*lo + lo*hi share one
+// accumulator (round 2 kept lo scaled by 2^11 in a second accumulator set: 64 more VGPRs per 128x128 tile, no room for wider
+// wave tiles).  For |x| < 2^-3 the lo half is an f16 subnormal: its absolute error is then at most 2^-25 - fp32-grade relative to
+// an operand tensor of RMS ~1, which BatchNorm outputs are.  v_mfma_f32_32x32x16_f16 keeps subnormal operands (measured on
+// gfx950: tools/probes/mfma_f16_denorm.hip).  Weights are small (|w| ~ 1e-2): their forward copy holds 2^8 w, which puts its lo
+// half back into the normal range; the convolution's epilogue multiplies by 2^-8.
+constexpr float P16_W_SCALE = 256.f;
 constexpr float P16_F16_LIMIT = 65504.f;        // |x| at or beyond this cannot be represented by the f16 pair
 
 __device__ __forceinline__ void p16_split2_bf16(float x0, float x1, unsigned& hi, unsigned& lo) {
@@ -23,7 +29,7 @@ __device__ __forceinline__ void p16_split2_f16(float x0, float x1, unsigned& hi,
     p16_f32x2 v; v[0] = x0; v[1] = x1;
     const p16_f16x2 h = __builtin_convertvector(v, p16_f16x2);                            // v_cvt_pk_f16_f32 (RNE)
     hi = __builtin_bit_cast(unsigned, h);
-    const p16_f32x2 r = (v - __builtin_convertvector(h, p16_f32x2)) * P16_LO_SCALE;       // residual exact, then 2^11
+    const p16_f32x2 r = v - __builtin_convertvector(h, p16_f32x2);                        // residual: exact in fp32
     lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, p16_f16x2));
 }
 
@@ -53,7 +59,7 @@ __device__ __forceinline__ void p16_load8(const void* group, float (&v)[8]) {
         if (F16) {
             const p16_f32x2 hf = __builtin_convertvector(__builtin_bit_cast(p16_f16x2, h), p16_f32x2);
             const p16_f32x2 lf = __builtin_convertvector(__builtin_bit_cast(p16_f16x2, l), p16_f32x2);
-            v[2 * e] = hf[0] + lf[0] * (1.f / P16_LO_SCALE); v[2 * e + 1] = hf[1] + lf[1] * (1.f / P16_LO_SCALE);
+            v[2 * e] = hf[0] + lf[0]; v[2 * e + 1] = hf[1] + lf[1];
         } else {
             v[2 * e] = __builtin_bit_cast(float, h << 16) + __builtin_bit_cast(float, l << 16);
             v[2 * e + 1] = __builtin_bit_cast(float, h & 0xFFFF0000u) + __builtin_bit_cast(float, l & 0xFFFF0000u);
@@ -97,8 +103,8 @@ __device__ __forceinline__ void p16_load4_f16(const void* base, int64_t f4_index
     const unsigned l0 = reinterpret_cast<const unsigned*>(g + 16)[0], l1 = reinterpret_cast<const unsigned*>(g + 16)[1];
     const p16_f32x2 a = __builtin_convertvector(__builtin_bit_cast(p16_f16x2, h0), p16_f32x2), b = __builtin_convertvector(__builtin_bit_cast(p16_f16x2, h1), p16_f32x2);
     const p16_f32x2 c = __builtin_convertvector(__builtin_bit_cast(p16_f16x2, l0), p16_f32x2), d = __builtin_convertvector(__builtin_bit_cast(p16_f16x2, l1), p16_f32x2);
-    v[0] = a[0] + c[0] * (1.f / P16_LO_SCALE); v[1] = a[1] + c[1] * (1.f / P16_LO_SCALE);
-    v[2] = b[0] + d[0] * (1.f / P16_LO_SCALE); v[3] = b[1] + d[1] * (1.f / P16_LO_SCALE);
+    v[0] = a[0] + c[0]; v[1] = a[1] + c[1];
+    v[2] = b[0] + d[0]; v[3] = b[1] + d[1];
 }
 // bit e set when element e of the lane's four is > 0 in a bf16 pair tensor (the hi half decides: bf16 keeps fp32's
 // exponent range, so hi > 0 <=> x > 0 for every normal x)

@@ -5,14 +5,16 @@
 
 namespace {
 
+// f16_scale: the f16 pair holds f16_scale * x (1 for activations, P16_W_SCALE for conv weights: p16.h)
 __global__ __launch_bounds__(256) void p16_pack_kernel(const float* __restrict__ x, int64_t n8, void* __restrict__ f16_out, void* __restrict__ bf16_out,
-                                                       int* __restrict__ overflow_flag) {
+                                                       int* __restrict__ overflow_flag, float f16_scale) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
         const f32x4 a = reinterpret_cast<const f32x4*>(x)[2 * i], b = reinterpret_cast<const f32x4*>(x)[2 * i + 1];
         const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
         if (f16_out) {
-            p16_store8<true>(reinterpret_cast<char*>(f16_out) + i * 32, v);
-            if (overflow_flag && p16_f16_overflow(v)) *overflow_flag = 1;
+            const float vs[8] = {v[0] * f16_scale, v[1] * f16_scale, v[2] * f16_scale, v[3] * f16_scale, v[4] * f16_scale, v[5] * f16_scale, v[6] * f16_scale, v[7] * f16_scale};
+            p16_store8<true>(reinterpret_cast<char*>(f16_out) + i * 32, vs);
+            if (overflow_flag && p16_f16_overflow(vs)) *overflow_flag = 1;
         }
         if (bf16_out) p16_store8<false>(reinterpret_cast<char*>(bf16_out) + i * 32, v);
     }
@@ -56,7 +58,8 @@ __global__ __launch_bounds__(256) void p16_pack_weights_multi_kernel(const int64
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
         if (wf != nullptr) {
             const f32x4 a = reinterpret_cast<const f32x4*>(w)[2 * i], b = reinterpret_cast<const f32x4*>(w)[2 * i + 1];
-            const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+            const float v[8] = {a[0] * P16_W_SCALE, a[1] * P16_W_SCALE, a[2] * P16_W_SCALE, a[3] * P16_W_SCALE,
+                                b[0] * P16_W_SCALE, b[1] * P16_W_SCALE, b[2] * P16_W_SCALE, b[3] * P16_W_SCALE};      // the forward copy holds 2^8 w (p16.h)
             p16_store8<true>(wf + i * 32, v);
             if (overflow_flag && p16_f16_overflow(v)) *overflow_flag = 1;
         }
@@ -83,7 +86,7 @@ extern "C" int bdetr_p16_pack_conv_weights_multi(const int64_t* table, int ntens
 
 extern "C" int bdetr_p16_pack(const float* x, int64_t n, void* f16_out, void* bf16_out, int* overflow_flag, void* stream) {
     BDETR_CHECK_ARG(x && n > 0 && n % 8 == 0 && (f16_out || bf16_out), "bdetr_p16_pack: bad arguments (n %% 8 == 0 required)");
-    hipLaunchKernelGGL(p16_pack_kernel, dim3(ew_grid(n / 8, 256, 2)), dim3(256), 0, (hipStream_t)stream, x, n / 8, f16_out, bf16_out, overflow_flag);
+    hipLaunchKernelGGL(p16_pack_kernel, dim3(ew_grid(n / 8, 256, 2)), dim3(256), 0, (hipStream_t)stream, x, n / 8, f16_out, bf16_out, overflow_flag, 1.f);
     return bdetr_launch_status("p16_pack");
 }
 
@@ -95,14 +98,14 @@ extern "C" int bdetr_p16_unpack(const void* p, int is_f16, int64_t n, float* out
 }
 
 // Both operand copies of one conv / dense weight tensor w [K][R][S][C] (OHWI):
-//   w_f16   P16-f16  [K][R*S*C]        forward B operand
+//   w_f16   P16-f16  [K][R*S*C]        forward B operand; holds 2^8 w (p16.h), the forward convolution rescales
 //   wt_bf16 P16-bf16 [C][R*S][K]       backward-data B operand (transposed, taps flipped)
 // Either output may be null.
 extern "C" int bdetr_p16_pack_conv_weights(const float* w, int K, int R, int S, int C, void* w_f16, void* wt_bf16, int* overflow_flag, void* stream) {
     BDETR_CHECK_ARG(w && K > 0 && R > 0 && S > 0 && C > 0 && K % 8 == 0 && C % 8 == 0, "bdetr_p16_pack_conv_weights: K and C must be multiples of 8");
     hipStream_t st = (hipStream_t)stream;
     const int64_t n = (int64_t)K * R * S * C;
-    if (w_f16) hipLaunchKernelGGL(p16_pack_kernel, dim3(ew_grid(n / 8, 256, 2)), dim3(256), 0, st, w, n / 8, w_f16, (void*)nullptr, overflow_flag);
+    if (w_f16) hipLaunchKernelGGL(p16_pack_kernel, dim3(ew_grid(n / 8, 256, 2)), dim3(256), 0, st, w, n / 8, w_f16, (void*)nullptr, overflow_flag, P16_W_SCALE);
     if (wt_bf16) hipLaunchKernelGGL(p16_pack_wt_kernel, dim3(ew_grid(n / 8, 256, 1)), dim3(256), 0, st, w, K, R, S, C, wt_bf16);
     return bdetr_launch_status("p16_pack_conv_weights");
 }

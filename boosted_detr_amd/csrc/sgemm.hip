@@ -18,6 +18,7 @@
 //
 // Replaces: Keras Conv2D and its autodiff inside tf.keras.applications ResNet-50 (backbone.py:37-38,57).
 #include "gemm_common.h"
+#include "p16.h"
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
@@ -30,7 +31,6 @@ namespace {
 constexpr int BK = 32;                          // reduction depth of one LDS stage
 constexpr unsigned OOB = 0xFFFFFFF0u;           // byte offset beyond num_records: the load writes zeros
 constexpr unsigned NUM_RECORDS = 0xFFFFFF00u;   // operands must span < 4 GB (checked on the host)
-constexpr float LO_SCALE = 2048.f;
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -519,8 +519,7 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
     };
 
     // ---------------- accumulators ----------------
-    constexpr int TM2 = F16 ? TM : 1, TN2 = F16 ? TN : 1;
-    f32x16 acc[TM][TN], acc2[TM2][TN2];       // acc2: the 2^11-scaled cross products of the f16 pair
+    f32x16 acc[TM][TN];                       // ONE accumulator set for all three split products, f16 pairs too (p16.h)
     auto zero_acc = [&]() {
         // an opaque zero: otherwise the persistent loop keeps whole zero-filled 16-register tuples alive across the K loop
         // as the "constant" it re-initialises the accumulators from
@@ -532,22 +531,6 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
             for (int b = 0; b < TN; ++b)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[a][b][e] = z;
-#pragma unroll
-        for (int a = 0; a < TM2; ++a)
-#pragma unroll
-            for (int b = 0; b < TN2; ++b)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc2[a][b][e] = z;
-    };
-    auto fold_acc2 = [&]() {
-        if constexpr (F16) {
-#pragma unroll
-            for (int a = 0; a < TM; ++a)
-#pragma unroll
-                for (int b = 0; b < TN; ++b)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[a][b][e] += acc2[a][b][e] * (1.f / LO_SCALE);
-        }
     };
     zero_acc();
 
@@ -601,8 +584,8 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
             for (int b = 0; b < TN; ++b) {
                 if constexpr (F16) {
 #define H8(v) __builtin_bit_cast(f16x8, v)
-                    acc2[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(al[a]), H8(bh[b]), acc2[a][b], 0, 0, 0);
-                    acc2[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(ah[a]), H8(bl[b]), acc2[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(al[a]), H8(bh[b]), acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(ah[a]), H8(bl[b]), acc[a][b], 0, 0, 0);
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(H8(ah[a]), H8(bh[b]), acc[a][b], 0, 0, 0);
 #undef H8
                 } else {
@@ -694,7 +677,6 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
             if (t + 1 < nk) step(t + 1, I1{}, I2{}, I0{});
             if (t + 2 < nk) step(t + 2, I2{}, I0{}, I1{});
         }
-        fold_acc2();
         if (XX && g.mode == ST_ATOMIC && g.bias == nullptr && g.act == BDETR_ACT_NONE && g.stat_sum == nullptr && !g.rowmap && g.ldc * 4 * BM < (1ll << 31)) {
             atomic_epilogue<BM, BN, WM, WN>(acc, g, i0, j0);
             return;
@@ -726,8 +708,7 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
                     kstep(1);
                 }
             }
-            fold_acc2();
-            const int e_tile_i = tile_i, e_i0 = i0, e_j0 = j0;
+                const int e_tile_i = tile_i, e_i0 = i0, e_j0 = j0;
             const int nvb = vb + (int)gridDim.x;
             const bool more = nvb < total;
             if (more) { locate(nvb); setup_rows(); }
@@ -781,7 +762,6 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
                 kstep(1);
             }
         }
-        fold_acc2();
         if (XX && g.mode == ST_ATOMIC && g.bias == nullptr && g.act == BDETR_ACT_NONE && g.stat_sum == nullptr && !g.rowmap && g.ldc * 4 * BM < (1ll << 31)) {
             atomic_epilogue<BM, BN, WM, WN>(acc, g, i0, j0);
             return;
@@ -946,8 +926,15 @@ extern "C" int bdetr_p16_supported(const bdetr_conv_desc* d) {
 
 static int fwd_tile(const bdetr_conv_desc* d) { return choose_tile((int64_t)d->N * d->OH * d->OW, d->K, 1, false); }
 
+// 3x3 / stride 1 / pad 1: the halo-resident kernel of hconv.hip (its tile as BM * 1000 + BN), else 0
+static int fwd_hconv(const bdetr_conv_desc* d) {
+    if (!(d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1)) return 0;
+    return hconv_tile((int64_t)d->N * d->H * d->W, d->W, d->C, d->K, true);
+}
+
 extern "C" int bdetr_p16_conv2d_fwd_stat_chunks(const bdetr_conv_desc* d) {
     if (check_conv(d, "bdetr_p16_conv2d_fwd_stat_chunks")) return -1;
+    if (const int ht = fwd_hconv(d)) return (int)cdiv64((int64_t)d->N * d->OH * d->OW, ht / 1000) * 4;      // tiles_i * WM (4 wave rows)
     const int t = fwd_tile(d);
     return (int)cdiv64((int64_t)d->N * d->OH * d->OW, TILE_BM[t]) * TILE_WM[t];          // tiles_i * WM
 }
@@ -961,6 +948,7 @@ extern "C" int bdetr_p16_conv2d_fwd(const void* x_f16, const void* w_f16, const 
     GemmParams g; init_params(g);
     g.I = M; g.J = d->K; g.R = Kd;
     g.c = y; g.ldc = d->K; g.bias = bias; g.act = act;
+    g.alpha = 1.f / P16_W_SCALE;                          // the weights' f16 pair copy holds 2^8 w (p16.h)
     g.stat_sum = stat_sum; g.stat_sq = stat_sq;
     PDense wop{w_f16, (unsigned)Kd, d->K, Kd};
     hipStream_t st = (hipStream_t)stream;
@@ -969,6 +957,7 @@ extern "C" int bdetr_p16_conv2d_fwd(const void* x_f16, const void* w_f16, const 
         PDense xop{x_f16, (unsigned)d->C, M, d->C};
         return launch_any<RRDense, RRDense, false, true>(xop, wop, g, 1, st, 0, tile);
     }
+    if (const int ht = fwd_hconv(d)) return hconv_launch(ht, true, x_f16, d->N, d->H, d->W, d->C, w_f16, d->K, g, st);
     PPatch xop = make_patch(x_f16, d->N, d->H, d->W, d->C, d->OH, d->OW, d->R, d->S, d->stride, d->pad, M, Kd);
     return launch_any<RRPatch, RRDense, false, true>(xop, wop, g, 1, st, 1000, tile);
 }

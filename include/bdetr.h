@@ -137,7 +137,10 @@ int bdetr_conv2d_bwd_weight_splitk(const bdetr_conv_desc* d);
  *
  * P16 layout of a row-major [rows][C] matrix, C % 8 == 0, 4 bytes per element like fp32: every group of 8
  * consecutive elements occupies 32 bytes = [8 x hi (16 bit)][8 x lo (16 bit)].
- *   f16 pair  (forward operands):  hi = f16(x),  lo = f16((x - hi) * 2^11);  |x| < 65504 or the value is lost
+ *   f16 pair  (forward operands):  hi = f16(x),  lo = f16(x - hi), unscaled;  |x| < 65504 or the value is lost.  For |x| < 2^-3 the
+ *             lo half is an f16 subnormal (absolute error <= 2^-25: fp32-grade against an operand tensor of RMS ~1; the MFMA keeps
+ *             subnormal operands).  The forward copy of a conv WEIGHT holds 2^8 w (weights are ~1e-2: their lo halves stay normal);
+ *             bdetr_p16_conv2d_fwd multiplies by 2^-8 in its epilogue.  All three split products share ONE accumulator.
  *   bf16 pair (gradient operands): hi = bf16(x), lo = bf16(x - hi);          fp32 range
  * The producer of a tensor writes it (bdetr_bn_apply_p16 / bdetr_bn_bwd_p16 / bdetr_p16_pack*), the GEMM moves
  * it HBM -> LDS with buffer_load ... lds and evaluates a product as three 16-bit MFMA products, fp32

@@ -332,26 +332,36 @@ def test_gemm_grouped_qkv(cuda):
         close(dx, dy.double() @ w.double())
 
 
+@pytest.mark.parametrize("policy", ["mixed", "split", "bf16x3", "fp32"])
 @pytest.mark.parametrize("B,h,nq,nk", [(2, 8, 400, 400), (2, 8, 100, 400), (3, 8, 100, 100), (2, 8, 49, 49), (1, 4, 50, 49), (1, 8, 300, 1050)])
-def test_fused_attention_fwd_bwd(cuda, B, h, nq, nk):
-    """csrc/attention.hip vs an fp64 reference of transformers.py:86-97 (incl. the [B,h,q,d] output layout)."""
+def test_fused_attention_fwd_bwd(cuda, B, h, nq, nk, policy):
+    """csrc/attention.hip vs an fp64 reference of transformers.py:86-97 (incl. the [B,h,q,d] output layout), under every
+    arithmetic policy: the forward is exact fp32 under 'mixed' / 'fp32', three split-f16 MFMA products under 'split' (fp32-grade),
+    three split-bf16 ones under 'bf16x3'; the gradients are split-bf16 (2^-18 per product) except under 'fp32'."""
     from boosted_detr_amd import kernels as k
     D = h * 32
     Q, Kt, V = rnd(B, nq, D, seed=1), rnd(B, nk, D, seed=2), rnd(B, nk, D, seed=3)
     Q[0, 0] *= 6.0                                   # a spiky row: exercises the online-softmax rescale
     dO = rnd(B, h, nq, 32, seed=4)
     scale = 1.0 / np.sqrt(32.0)
-    o, lse = k.attention_fwd(dev(Q), dev(Kt), dev(V), h, scale)
+    with k.gemm_precision(policy):
+        o, lse = k.attention_fwd(dev(Q), dev(Kt), dev(V), h, scale)
     Qd, Kd, Vd = (t.double().requires_grad_(True) for t in (Q, Kt, V))
     Qh = Qd.view(B, nq, h, 32).permute(0, 2, 1, 3)
     Kh = Kd.view(B, nk, h, 32).permute(0, 2, 3, 1)
     Vh = Vd.view(B, nk, h, 32).permute(0, 2, 1, 3)
     s = (Qh @ Kh) * scale
     ref = torch.softmax(s, -1) @ Vh                                  # [B,h,q,32]
-    close(o, ref, rtol=1e-5)
-    close(lse, torch.logsumexp(s, -1), rtol=1e-5)
+    fwd_tol = 5e-5 if policy == "bf16x3" else 1e-5
+    close(o, ref, rtol=fwd_tol)
+    close(lse, torch.logsumexp(s, -1), rtol=fwd_tol)
     ref.backward(dO.double())
-    dq, dk, dv = k.attention_bwd(dev(Q), dev(Kt), dev(V), o, dev(dO), lse, h, scale)
-    close(dq, Qd.grad, rtol=5e-5)
-    close(dk, Kd.grad, rtol=5e-5)
-    close(dv, Vd.grad, rtol=5e-5)
+    with k.gemm_precision(policy):
+        dq, dk, dv = k.attention_bwd(dev(Q), dev(Kt), dev(V), o, dev(dO), lse, h, scale)
+    # Gradients under split-bf16: dS = P (dP - D) cancels for a peaked row (the spiky query: P ~ one-hot, dP ~ D), so dS carries
+    # the 2^-18 product error of dP relative to |dP|, not to |dS| - measured worst 8e-5 of max|dK| on these inputs (the convolutions'
+    # gradient bar is 6e-5, the end-to-end bound of test_backward_arithmetic_in_isolation 2e-4); exact fp32 holds 5e-5
+    bwd_tol = 5e-5 if policy == "fp32" else 2e-4
+    close(dq, Qd.grad, rtol=bwd_tol)
+    close(dk, Kd.grad, rtol=bwd_tol)
+    close(dv, Vd.grad, rtol=bwd_tol)
