@@ -265,12 +265,14 @@ def main():
                     "step's encoder output) to every step: --backbone ResNet101 --image 800 --image-w 1333 --queries 300 --batch 8 --panoptic")
     ap.add_argument("--no-fp32-policy", action="store_true", help="skip the secondary measurement under the exact-fp32 arithmetic policy")
     ap.add_argument("--no-batch32", action="store_true", help="skip the secondary measurement at configs[3]'s per-GPU batch (32)")
-    ap.add_argument("--graph", action="store_true", help="replay the step as captured hipGraph segments (Model.use_graph) instead of enqueuing it from Python")
+    ap.add_argument("--graph", action="store_true", help="(default at N=1) replay the step as captured hipGraph segments (Model.use_graph) instead of enqueuing it from Python")
+    ap.add_argument("--no-graph", action="store_true", help="enqueue every step from Python (the N>1 runs always do: the collectives are issued from the backward pass)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
     overrides = env_overrides()               # refuses diagnostic switches; everything else that is set goes into the line
 
+    import boosted_detr_amd                   # first: it sets the hipGraph runtime switch before this process initialises HIP
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -320,7 +322,7 @@ def main():
 
     if distributed:
         model.distribute()
-    model.use_graph = args.graph and not distributed       # N > 1: the collectives are issued per bucket from the backward pass (eager)
+    model.use_graph = not args.no_graph and not distributed and os.environ.get("BDETR_GRAPH", "1") != "0"   # N > 1: collectives are issued per bucket from the backward pass (eager)
 
     def note(msg):
         if rank == 0:
@@ -334,6 +336,16 @@ def main():
         if args.panoptic:
             masks[0] = model.panoptic_masks()
 
+    if model.use_graph:
+        # build-by-first-call, allocator warm-up and the capture itself (third step on a signature) are set-up, like the build:
+        # they happen before the W warm-up steps, so that warm-up and timed steps are all replays whatever W is
+        for i in range(4):
+            tw = time.perf_counter()
+            run_step(batch)
+            torch.cuda.synchronize()
+            note(f"set-up step {i} ({'captured' if model._graphs else 'eager'}): {(time.perf_counter() - tw) * 1e3:.1f} ms")
+            if model._graphs:
+                break
     for i in range(max(args.warmup, 1)):
         tw = time.perf_counter()
         run_step(batch)
@@ -362,7 +374,10 @@ def main():
     torch.cuda.synchronize()
     guard = {"range_redos_in_timed_region": model.range_redos - redos_before, "update_free_attempts": model.range_skipped,
              "overflow_flag_after_run": int(K.overflow_flag().item()), "policy_guarded": bool(model._guarded()),
-             "check": "async flag snapshot after every step, examined 2 steps later (Model._guard_poll)"}
+             "check": "the flag is logged to pinned memory by the last kernel of every step and examined 2 steps later (Model._guard_poll)"}
+
+    step_launch = "hipGraph replay (segmented)" if model._graphs else "eager"
+    model.use_graph = False                   # the secondary legs below (per-launch events, other batch sizes / policies) enqueue eagerly
 
     # Data-parallel legs (N > 1): a few more steps with events on the communication stream around every bucket's all-reduce.
     allreduce = None
@@ -396,7 +411,6 @@ def main():
         from boosted_detr_amd import engine as _engine
         side_was = _engine._SIDE["enabled"]
         _engine.set_side_stream_enabled(False)
-        graph_was, model.use_graph = model.use_graph, False          # per-launch hipEvents need eager launches
         L.bdetr_prof_enable(1 if rank == 0 else 0)
         t1 = time.perf_counter()
         for _ in range(args.steps):
@@ -404,7 +418,6 @@ def main():
         torch.cuda.synchronize()
         prof_wall = time.perf_counter() - t1
         _engine.set_side_stream_enabled(side_was)
-        model.use_graph = graph_was
     if want_roof and rank == 0:
         ms, n, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
         _lib.check(L.bdetr_prof_read(ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)), "prof_read")
@@ -511,7 +524,8 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": dtype_note(model), "arithmetic": arithmetic_note(model), "data": "synthetic",
             "config": {"workload": workload_name(args), "per_gpu_batch": args.batch, "global_batch": global_batch,
-                       "parallelism": f"dp{world}", "step_launch": "hipGraph replay" if model.use_graph else "eager", "gflop_per_image_algorithmic": gflop_img,
+                       "parallelism": f"dp{world}", "step_launch": step_launch,
+                       "runtime_switches": {"DEBUG_CLR_GRAPH_PACKET_CAPTURE": os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE")}, "gflop_per_image_algorithmic": gflop_img,
                        "configs3": b32, "env_overrides": overrides, "distributed": dist_info},
             "tflops_algorithmic": round(value * gflop_img / 1e3, 2) if gflop_img else None,
             "final_loss": round(logs.get("loss", float("nan")), 4),

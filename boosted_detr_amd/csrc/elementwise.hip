@@ -206,6 +206,28 @@ extern "C" int bdetr_tokens_prepare(const int* cat_ids, const int* att_ids, int6
     return bdetr_launch_status("tokens_prepare");
 }
 
+// Last kernel of a guarded training step (eager or inside the captured optimizer segment): one lane advances the device-resident
+// step ordinal and logs the guard word against it in host-visible (pinned, device-mapped) memory - ring[1 + ordinal % len] = *flag,
+// then ring[0] = ordinal, system-scope stores with a system fence between.  A host that finds ring[0] >= k may read the entry of
+// step k without synchronising the stream.  Part of the step, not an operation enqueued between steps: a device operation that reads
+// the guard word BETWEEN the hipGraph launches of a segmented step (a D2H memcpy or a kernel alike) corrupted the replays that
+// followed on ROCm 7.2 (round 3, tools/graph_debug.py), one inside the captured segment does not.
+__global__ void flag_snapshot_kernel(const int* __restrict__ flag, int* __restrict__ ordinal, int* ring, int ring_len) {
+    if (threadIdx.x == 0) {
+        const int k = *ordinal + 1;
+        *ordinal = k;
+        __hip_atomic_store(&ring[1 + k % ring_len], *flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __threadfence_system();
+        __hip_atomic_store(&ring[0], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+extern "C" int bdetr_flag_snapshot(const int* flag, int* ordinal, int* host_ring, int ring_len, void* stream) {
+    BDETR_CHECK_ARG(flag && ordinal && host_ring && ring_len > 0, "bdetr_flag_snapshot: bad arguments");
+    hipLaunchKernelGGL(flag_snapshot_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, flag, ordinal, host_ring, ring_len);
+    return bdetr_launch_status("flag_snapshot");
+}
+
 extern "C" int bdetr_flag_nonfinite(const float* x, int64_t n, int* flag, void* stream) {
     BDETR_CHECK_ARG(x && flag && n > 0, "bdetr_flag_nonfinite: bad arguments");
     hipLaunchKernelGGL(flag_nonfinite_kernel, dim3(ew_grid(n, 256, 4)), dim3(256), 0, (hipStream_t)stream, x, n, flag);

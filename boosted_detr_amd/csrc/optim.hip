@@ -29,13 +29,17 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const uint64_t* __restrict_
     if (threadIdx.x == 0) partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+// guard (optional): raised when a tensor's gradient norm is not finite - a NaN / Inf born in the backward pass, which the loss
+// check of the range guard cannot see; sgd_apply_kernel (the next launch) then applies nothing at all.
 __global__ __launch_bounds__(256) void norm_final_kernel(const float* __restrict__ partial, const int64_t* __restrict__ slab_first, int ntensors,
-                                                         float* __restrict__ norms) {
+                                                         float* __restrict__ norms, int* __restrict__ guard) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ntensors) return;
     double s = 0;
     for (int64_t k = slab_first[t]; k < slab_first[t + 1]; ++k) s += partial[k];
-    norms[t] = (float)sqrt(s);
+    const float nrm = (float)sqrt(s);
+    norms[t] = nrm;
+    if (guard != nullptr && !(fabsf(nrm) <= 3.0e38f)) *guard = 1;
 }
 
 __global__ __launch_bounds__(256) void sgd_apply_kernel(const uint64_t* __restrict__ ptrs, const int64_t* __restrict__ sizes,
@@ -72,12 +76,12 @@ extern "C" int bdetr_sgd_slab_elems(void) { return SLAB; }
 extern "C" int bdetr_sgd_nesterov_clipnorm(const uint64_t* ptrs, const int64_t* sizes, int ntensors,
                                            const int64_t* slab_tensor, const int64_t* slab_first, int nslabs,
                                            float* partial, float* norms, const float* lr, float momentum,
-                                           float clipnorm, float grad_scale, const int* skip_flag, void* stream) {
+                                           float clipnorm, float grad_scale, int* skip_flag, void* stream) {
     BDETR_CHECK_ARG(ptrs && sizes && slab_tensor && slab_first && partial && norms && lr && ntensors > 0 && nslabs > 0,
                     "bdetr_sgd_nesterov_clipnorm: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(sqnorm_kernel, dim3(nslabs), dim3(256), 0, st, ptrs, sizes, slab_tensor, slab_first, partial);
-    hipLaunchKernelGGL(norm_final_kernel, dim3((ntensors + 255) / 256), dim3(256), 0, st, partial, slab_first, ntensors, norms);
+    hipLaunchKernelGGL(norm_final_kernel, dim3((ntensors + 255) / 256), dim3(256), 0, st, partial, slab_first, ntensors, norms, skip_flag);
     hipLaunchKernelGGL(sgd_apply_kernel, dim3(nslabs), dim3(256), 0, st, ptrs, sizes, slab_tensor, slab_first, norms, lr, momentum, clipnorm, grad_scale, skip_flag);
     return bdetr_launch_status("sgd_nesterov_clipnorm");
 }

@@ -242,10 +242,13 @@ class Tape:
                         grads[key] = s
                 else:
                     grads[key] = g
+            if _CAPTURE[0] is not None:
+                _CAPTURE[0].maybe_cut()            # segmented graph capture: cut between tape nodes once enough side tasks are pending
         return grads
 
 
 _TAPE: Optional[Tape] = None
+_CAPTURE = [None]            # the SegmentedCapture in progress (defined below), or None
 
 # ----------------------------------------------------------------------------------------
 # side stream: weight-gradient GEMMs run off the critical path
@@ -310,6 +313,102 @@ class on_side_stream:
             K.set_launch_stream(self.prev_handle)
             self.ctx.__exit__(*exc)
         return False
+
+
+# ----------------------------------------------------------------------------------------
+# segmented capture: the step as a CHAIN of hipGraphs with the weight-gradient work in graphs of its own
+# ----------------------------------------------------------------------------------------
+# One hipGraph of the whole step cannot keep the side stream: captured as a forked branch its ~110 main -> side edges made the
+# replay twice as slow (round 2), and captured in stream order the weight-gradient GEMMs no longer overlap anything.  Instead the
+# step is captured as main segments M_0 .. M_k (the critical path, cut between tape nodes of the backward pass) and side segments
+# S_0 .. S_k (the weight / bias gradient tasks whose operands M_i produced).  Replay: M_i on the main stream, an event, S_i on
+# the low-priority side stream behind that event - S_i overlaps M_{i+1} - and one join before the optimizer segment.  Two private
+# memory pools: graphs that replay concurrently must not share one (an allocation freed during the capture of S_i could be handed
+# to M_{i+1}); tensors that cross (the operands of the side tasks) are kept alive by the deferred closures until the capture ends.
+
+
+class SegmentedCapture:
+    SIDE_TASKS_PER_SEGMENT = int(_os.environ.get("BDETR_GRAPH_SEG", "10"))
+
+    def __init__(self):
+        self.pool_main, self.pool_side = torch.cuda.graph_pool_handle(), torch.cuda.graph_pool_handle()
+        self.cap_main, self.cap_side = torch.cuda.Stream(device=device()), torch.cuda.Stream(device=device())
+        self.mains, self.sides = [], []            # sides[i] (or None) runs behind mains[i]
+        self.pending, self.done = [], []           # deferred side tasks of the open segment / closures kept alive until the end
+        self._cur = None
+
+    def begin_main(self) -> None:
+        g = torch.cuda.CUDAGraph()
+        ctx = torch.cuda.graph(g, pool=self.pool_main, stream=self.cap_main)
+        ctx.__enter__()
+        self._cur = (g, ctx)
+        K.set_launch_stream(self.cap_main.cuda_stream)
+
+    def end_main(self) -> None:
+        g, ctx = self._cur
+        ctx.__exit__(None, None, None)
+        self.mains.append(g)
+        self._cur = None
+
+    def capture_side(self) -> None:
+        if not self.pending:
+            self.sides.append(None)
+            return
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=self.pool_side, stream=self.cap_side):
+            prev = K.set_launch_stream(self.cap_side.cuda_stream)
+            try:
+                for fn in self.pending:
+                    fn()
+            finally:
+                K.set_launch_stream(prev)
+        self.sides.append(g)
+        self.done.extend(self.pending)
+        self.pending = []
+
+    def cut(self) -> None:
+        """Close the open main segment, capture its side tasks, open the next main segment."""
+        self.end_main()
+        self.capture_side()
+        self.begin_main()
+
+    def maybe_cut(self) -> None:
+        if len(self.pending) >= self.SIDE_TASKS_PER_SEGMENT:
+            self.cut()
+
+    def replay(self, side) -> None:
+        """mains[i] on the current stream, sides[i] on `side` behind an event; the LAST main segment (optimizer) waits for the side stream.
+        Needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (graph_replay_is_safe below)."""
+        main = torch.cuda.current_stream()
+        last = len(self.mains) - 1
+        used = False
+        for i, g in enumerate(self.mains):
+            if i == last and used:
+                main.wait_stream(side)
+            g.replay()
+            sg = self.sides[i] if i < len(self.sides) else None
+            if sg is None:
+                continue
+            if side is None:                       # side stream switched off: the same graphs, in stream order
+                sg.replay()
+                continue
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                sg.replay()
+            used = True
+
+
+def side_task(fn, *keep) -> None:
+    """Run `fn` (weight / bias gradient launches that nobody on the critical path consumes) on the side stream - or, while a step is
+    being captured in segments, defer it into the side graph of the open segment."""
+    cap = _CAPTURE[0]
+    if cap is not None:
+        cap.pending.append(fn)
+        return
+    with on_side_stream(*keep):
+        fn()
 
 
 def join_side_stream() -> None:

@@ -247,6 +247,14 @@ def flag_nonfinite(x: torch.Tensor) -> None:
     check(_lib.lib().bdetr_flag_nonfinite(_p(x), x.numel(), _p(overflow_flag()), _stream()), "flag_nonfinite")
 
 
+def flag_snapshot(ordinal: torch.Tensor, host_ring: torch.Tensor) -> None:
+    """Log the overflow flag against the step ordinal in a pinned int32[1 + n] host tensor: ordinal += 1 (device int32),
+    host_ring[1 + ordinal % n] = flag, host_ring[0] = ordinal.  One lane on the launch stream, capturable, no D2H memcpy, no sync."""
+    assert host_ring.dtype == torch.int32 and host_ring.numel() >= 2 and host_ring.is_pinned()
+    assert ordinal.dtype == torch.int32 and ordinal.is_cuda
+    check(_lib.lib().bdetr_flag_snapshot(_p(overflow_flag()), _p(ordinal), host_ring.data_ptr(), host_ring.numel() - 1, _stream()), "flag_snapshot")
+
+
 def read_and_clear_overflow() -> bool:
     """Host read of the range guard (synchronises the device)."""
     f = overflow_flag()

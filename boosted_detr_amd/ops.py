@@ -16,7 +16,7 @@ from typing import Optional
 import torch
 
 from . import kernels as K
-from .engine import WEIGHTS_VERSION, Variable, current_tape, materialise, on_side_stream
+from .engine import WEIGHTS_VERSION, Variable, current_tape, materialise, side_task
 
 # Dropout masks are keyed by (per-step seed, dropout site, element index).  The per-step seed lives in HBM
 # (one int64 the host rewrites before every step), the site salt is a launch argument: a captured step graph then
@@ -321,7 +321,7 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
             sb.commit()
             dyb4 = dyb.view(N, g.OH, g.OW, Kout)
             if w.needs_grad or b.needs_grad:
-                with on_side_stream(xb, dyb):
+                def param_grads(xb=xb, dyb4=dyb4):
                     if w.needs_grad:
                         s = GradSink(w)
                         K.p16_conv2d_bwd_weight(xb, dyb4, g, dw=s.buf, prezeroed=s.mode == "direct")
@@ -331,6 +331,7 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
                         if s.mode != "direct":
                             K.zero_(s.buf)
                         s.commit()
+                side_task(param_grads, xb, dyb)
             dx = None
             if x_needs_grad:
                 _, wt = packed_weights(w, need_bwd=True)
@@ -360,7 +361,7 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
         dy, dres = _bn_backward(g2d, out32, y2d, mean, rstd, bn, relu, not use_batch, want_res)
         dy4 = dy.view(N, g.OH, g.OW, Kout)
         if w.needs_grad or b.needs_grad:
-            with on_side_stream(x32, dy):
+            def param_grads(x32=x32, dy=dy, dy4=dy4):
                 if w.needs_grad:
                     s = GradSink(w)
                     K.conv2d_bwd_weight(x32, dy4, g, dw=s.buf, prezeroed=s.mode == "direct")
@@ -375,6 +376,7 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
                     else:
                         K.colsum(dy, out=s.buf, prezeroed=s.mode == "direct")
                     s.commit()
+            side_task(param_grads, x32, dy)
         dx = None
         if x_needs_grad:
             if acc is not None and acc[0] is not None:
@@ -408,7 +410,7 @@ def conv_act(x: torch.Tensor, w: Variable, b: Variable, stride: int, pad: int, a
         else:
             dpre = g_out
         if w.needs_grad or b.needs_grad:
-            with on_side_stream(x, dpre):
+            def param_grads(dpre=dpre):
                 if w.needs_grad:
                     s = GradSink(w)
                     K.conv2d_bwd_weight(x, dpre, g, dw=s.buf, prezeroed=s.mode == "direct")
@@ -417,6 +419,7 @@ def conv_act(x: torch.Tensor, w: Variable, b: Variable, stride: int, pad: int, a
                     s = GradSink(b)
                     K.colsum(_2d(dpre), out=s.buf, prezeroed=s.mode == "direct")
                     s.commit()
+            side_task(param_grads, x, dpre)
         return (_own(K.conv2d_bwd_data(dpre, w.value, g)),)
 
     _rec([y], [x], backward)
@@ -461,7 +464,7 @@ def dense(x: torch.Tensor, w: Variable, b: Variable, act: int = K.ACT_NONE) -> t
         elif act == K.ACT_TANH:
             g2d = K.tanh_bwd(y2d, g2d)
         if w.needs_grad or b.needs_grad:
-            with on_side_stream(x2d, g2d):
+            def param_grads(g2d=g2d):
                 if w.needs_grad:
                     s = GradSink(w)
                     K.linear_bwd_weight(g2d, x2d, dw=s.buf, prezeroed=s.mode == "direct")
@@ -470,6 +473,7 @@ def dense(x: torch.Tensor, w: Variable, b: Variable, act: int = K.ACT_NONE) -> t
                     s = GradSink(b)
                     K.colsum(g2d, out=s.buf, prezeroed=s.mode == "direct")
                     s.commit()
+            side_task(param_grads, x2d, g2d)
         have = acc[0] if acc is not None else None
         if have is not None and have.is_contiguous() and have.shape == x.shape:
             # another consumer's gradient of x is already there: add into it in the GEMM epilogue (no separate axpy pass)
@@ -497,7 +501,7 @@ def dense_group(xs, ws, bs):
         g2 = [_2d(g.contiguous()) for g in gs]
         for g, x, w, b in zip(g2, x2, ws, bs):
             if w.needs_grad or b.needs_grad:
-                with on_side_stream(x, g):
+                def param_grads(g=g, x=x, w=w, b=b):
                     if w.needs_grad:
                         s = GradSink(w)
                         K.linear_bwd_weight(g, x, dw=s.buf, prezeroed=s.mode == "direct")
@@ -506,6 +510,7 @@ def dense_group(xs, ws, bs):
                         s = GradSink(b)
                         K.colsum(g, out=s.buf, prezeroed=s.mode == "direct")
                         s.commit()
+                side_task(param_grads, x, g)
         dxs = K.linear_bwd_data_group(g2, [w.value for w in ws])
         return tuple(_own(dx.view(x.shape)) for dx, x in zip(dxs, xs))
 

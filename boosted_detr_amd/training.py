@@ -436,15 +436,15 @@ class Model(Layer):
         # Range guard of the 'split' policy: the f16 pairs of its forward products hold |x| < 65504, the reference's
         # fp32 does not overflow there.  Producers raise a device flag instead of feeding NaN downstream; while it is
         # up the optimizer applies nothing and moving statistics stay put.  The host learns of it WITHOUT synchronising:
-        # every step ends with an asynchronous 4-byte copy of the flag into pinned memory, and the next step looks at the
-        # snapshots whose copies have completed (`_guard_poll`).  Every batch from the one that raised the flag on is then
+        # every step ends with a one-lane kernel that logs the flag in pinned memory, and a later step looks at the
+        # entries that have landed (`_guard_poll`).  Every batch from the one that raised the flag on is then
         # redone on the exact-fp32 forward ('mixed') and the step / learning-rate counters are rolled back for the
         # update-free attempts, so no batch is lost and the schedule does not run ahead.
         self.guard_check_every = 1       # 0 disables the host side of the guard
         self.range_redos = 0             # guarded steps that were redone on the exact-fp32 forward
         self.range_skipped = 0           # ... how many update-free attempts that covered (counters rolled back for each)
         self._guard_count = 0
-        self._guard_pending: List[tuple] = []      # (step's batch, pinned snapshot of the flag after that step, its copy event)
+        self._guard_pending: List[tuple] = []      # (step's batch, its ordinal in the pinned flag log, the event recorded behind it)
         self._guard_was = None
         self.use_graph = os.environ.get("BDETR_GRAPH", "0") == "1"      # capture train_step as a hipGraph (see _graph_step)
         self._graphs, self._graph_warm = {}, {}
@@ -523,6 +523,9 @@ class Model(Layer):
                 with recording(tape):
                     y_pred = self(data, training=True)
                 tape.backward({id(t): t for t in self._loss_roots})     # parameter gradients land in Variable.grad (ops.GradSink)
+                from . import engine as _engine
+                if _engine._CAPTURE[0] is not None:
+                    _engine._CAPTURE[0].cut()        # segmented capture: close the backward's last segment (its side tasks need this step's sinks)
             self._kept_tape = tape if keep_tape else None
         finally:
             K.set_launch_stream(prev)
@@ -557,18 +560,27 @@ class Model(Layer):
             ops.set_live_flat_grad(None)
         join_side_stream()
 
-    # -- the step as a hipGraph ----------------------------------------------------------------------------
+    # -- the step as a chain of hipGraphs ------------------------------------------------------------------
     # ~1500 kernel launches, ~1300 allocator calls and the Python tape make up 20 ms of host work per step.  With
     # ``use_graph`` the third step on a given input signature is captured (torch.cuda.graph: the caching allocator
-    # hands the capture a private pool, so every intermediate of the step lives at a fixed address) and later steps
+    # hands the capture private pools, so every intermediate of the step lives at a fixed address) and later steps
     # copy the batch into the captured input tensors, write the two per-step scalars (dropout seed, learning rate)
     # to HBM and replay.  The reference's equivalent is tf.function / XLA (DETR_COCO.ipynb cell 3 enables the JIT).
-    # Measured on MI355X / ROCm 7.2 (config 2, batch 16): eager + side stream 477 images/s; graph of the single-stream
-    # step 447 (4 % faster than the same step enqueued eagerly, 429: no launch gaps); graph WITH the side-stream branch
-    # 256 (the ~110 main->side edges are expensive in hipGraph's executor).  The capture therefore keeps the
-    # weight-gradient GEMMs in stream order, and the mode is opt-in: it trades 6 % of throughput for a host-free step.
+    # Round 2 captured ONE graph in stream order (the side-stream branch as a forked capture cost 2x: ~110 cross-stream
+    # edges) and lost the overlap of the weight-gradient GEMMs: 447 images/s against 477-490 eager.  Round 3 captures a chain
+    # of graphs instead (engine.SegmentedCapture): the overlap is kept at segment granularity with a dozen cross-stream
+    # events per step, and the step stays host-free.
     def _graph_signature(self, data: dict):
         if not self.use_graph or self._dp is not None or self.validate_matching:
+            return None
+        from . import graph_replay_is_safe
+        if not graph_replay_is_safe():
+            if not getattr(self, "_graph_refused", False):
+                import sys
+                self._graph_refused = True
+                print("[boosted_detr_amd] use_graph: DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 was not in force when the HIP runtime initialised "
+                      "(import boosted_detr_amd before the first CUDA call, or export it) - hipGraph replays are not sound without it "
+                      "on ROCm 7.2; running eager steps", file=sys.stderr)
             return None
         if not all(isinstance(v, torch.Tensor) and v.is_cuda for v in data.values()):
             return None
@@ -584,7 +596,7 @@ class Model(Layer):
         opt = self.optimizer
         hyper = (opt.momentum, opt.nesterov, opt.clipnorm) if opt is not None else ()
         return (id(opt), tuple(getattr(opt, "_built_for", None) or ()), tuple(id(v) for v in self.trainable_variables),
-                transformers.AttentionBlock.dropout_rate, transformers.FeedForwardBlock.dropout_rate, loss, hyper)
+                bool(self.guard_check_every), transformers.AttentionBlock.dropout_rate, transformers.FeedForwardBlock.dropout_rate, loss, hyper)
 
     def _device_step(self, data: dict, stage_scalars: bool) -> Dict[str, list]:
         """Everything of a training step that runs on the device; no host synchronisation."""
@@ -601,6 +613,7 @@ class Model(Layer):
             if guard is not None:
                 self._dp.any_(guard)
         self.optimizer.apply_gradients(skip_flag=guard, stage_lr=stage_scalars)
+        self._guard_snapshot()
         self.steps_done += 1
         return self.step_logs()
 
@@ -615,28 +628,38 @@ class Model(Layer):
             ops.set_dropout_seed(self._step_seed())          # the captured kernels read both scalars from HBM
             self.optimizer.stage_lr()
             keep = (self.steps_done, self.optimizer.iterations)
-            from .engine import _SIDE, set_side_stream_enabled
-            side_was = _SIDE["enabled"]
-            set_side_stream_enabled(False)                   # one chain: see the measurements above
-            g = torch.cuda.CUDAGraph()
+            # The step is captured as a chain of graphs (engine.SegmentedCapture): main segments cut between tape nodes of the
+            # backward pass, the weight-gradient tasks of each in a side graph that replays on the low-priority stream while
+            # the next main segment runs, the optimizer in the last main segment behind the join.
+            from . import engine as _engine
+            cap = _engine.SegmentedCapture()
+            _engine._CAPTURE[0] = cap
+            prev_launch = K.set_launch_stream(None)
             try:
-                with torch.cuda.graph(g):
-                    logs = self._device_step(static, stage_scalars=False)
+                cap.begin_main()
+                logs = self._device_step(static, stage_scalars=False)
+                cap.end_main()
+                cap.sides.append(None)                       # (the optimizer segment has no side work)
             finally:
-                set_side_stream_enabled(side_was)
+                _engine._CAPTURE[0] = None
+                K.set_launch_stream(prev_launch)
+            cap.done = []                                    # the deferred closures kept the crossing tensors alive during the capture
             self.steps_done, self.optimizer.iterations = keep         # capturing is not a step
-            entry = (g, static, logs, (list(self._step_losses), list(self._loss_roots), dict(self._step_metrics)))
+            entry = (cap, static, logs, (list(self._step_losses), list(self._loss_roots), dict(self._step_metrics)))
             self._graphs[sig] = entry
-        g, static, logs, book = entry
+        cap, static, logs, book = entry
         for k, v in data.items():
             if v is not static[k]:
                 static[k].copy_(v)
         ops.set_dropout_seed(self._step_seed())
         self.optimizer.stage_lr()
-        g.replay()
+        from .engine import side_stream
+        cap.replay(side_stream() if os.environ.get("BDETR_GRAPH_SIDE", "1") != "0" else None)
         self._step_losses, self._loss_roots, self._step_metrics = list(book[0]), list(book[1]), dict(book[2])
         self.steps_done += 1
         self.optimizer.iterations += 1
+        if self._guarded() and self.guard_check_every:
+            self._guard_launched += 1                # the replayed optimizer segment ended with the snapshot kernel
         bump_weights_version()
         return logs
 
@@ -647,33 +670,48 @@ class Model(Layer):
         return logs
 
     GUARD_LAG = 2        # steps between a snapshot and the host's look at it
+    GUARD_RING = 8       # per-step entries of the pinned log (> GUARD_LAG + 1, the most that are ever pending)
+
+    def _guard_snapshot(self) -> None:
+        """Last launch of a guarded step: log the flag against the device-resident step ordinal in pinned memory (K.flag_snapshot).
+        Inside the step - and so inside the captured optimizer segment under use_graph - rather than between steps: see
+        bdetr_flag_snapshot (include/bdetr.h) for what an operation that reads the flag between graph launches did."""
+        if not (self._guarded() and self.guard_check_every):
+            return
+        if self.__dict__.get("_guard_host") is None:
+            self._guard_host = torch.zeros(1 + self.GUARD_RING, dtype=torch.int32).pin_memory()
+            self._guard_ordinal = torch.zeros(1, dtype=torch.int32, device="cuda")
+            self._guard_events = [torch.cuda.Event() for _ in range(self.GUARD_RING)]
+            self._guard_launched = 0
+        K.flag_snapshot(self._guard_ordinal, self._guard_host)
+        from . import engine as _engine
+        if _engine._CAPTURE[0] is None:
+            self._guard_launched += 1              # (a capture only records the launch; each replay counts, in _graph_step)
 
     def _guard_poll(self, data: dict, logs, force: bool = False):
-        """Host side of the range guard without stalling the device: every step ends with an asynchronous 4-byte copy of the
-        flag into pinned memory; step t looks at the snapshot of step t - GUARD_LAG, whose copy has long landed (the wait on
-        its event only bounds how far the host runs ahead).  A fixed lag, not a poll, so that data-parallel replicas - whose
-        flags agree after the step's MAX all-reduce - take the same decision at the same step.  A raised snapshot names the
-        step that left the fp16 range; that batch and the later ones ran without an update (the optimizer skips while the
-        flag is up), so all of them are redone on the exact-fp32 forward and the counters are rolled back for the
-        update-free attempts.  force: resolve every outstanding snapshot now (fit() reads the logs on the host anyway)."""
-        # (a small ring of pinned words and events, reused: a pinned allocation per step costs more than the step's whole guard)
-        n = self.GUARD_LAG + 2                    # at most GUARD_LAG + 1 snapshots are pending at any time
-        ring = self.__dict__.get("_guard_ring")
-        if ring is None:
-            ring = self._guard_ring = [(torch.empty(1, dtype=torch.int32, pin_memory=True), torch.cuda.Event()) for _ in range(n)]
-            self._guard_slot = -1
-        self._guard_slot = (self._guard_slot + 1) % n
-        snap, ev = ring[self._guard_slot]
-        snap.copy_(K.overflow_flag(), non_blocking=True)
+        """Host side of the range guard without stalling the device: every guarded step ends with a one-lane kernel that logs the
+        flag in pinned memory (`_guard_snapshot`); step t looks at the entry of step t - GUARD_LAG, which has long landed (the
+        wait on its event only bounds how far the host runs ahead).  A fixed lag, not a poll, so that data-parallel replicas -
+        whose flags agree after the step's MAX all-reduce - take the same decision at the same step.  A raised entry names the
+        step that left the fp16 range; that batch and the later ones ran without an update (the optimizer skips while the flag
+        is up), so all of them are redone on the exact-fp32 forward and the counters are rolled back for the update-free
+        attempts.  force: resolve every outstanding entry now (fit() reads the logs on the host anyway)."""
+        if self.__dict__.get("_guard_host") is None:
+            return logs                            # (no guarded step has run yet)
+        ev = self._guard_events[self._guard_launched % self.GUARD_RING]
         ev.record()
-        self._guard_pending.append((data, snap, ev))
+        self._guard_pending.append((data, self._guard_launched, ev))
         return self._guard_resolve(logs, 0 if force else self.GUARD_LAG)
 
     def _guard_resolve(self, logs, keep: int):
+        host = self._guard_host
         while len(self._guard_pending) > keep:
-            _, sn, e = self._guard_pending[0]
-            e.synchronize()
-            if int(sn[0]) != 0:
+            _, k, e = self._guard_pending[0]
+            if int(host[0]) < k:                     # (not landed yet: normally it has, GUARD_LAG steps later)
+                e.synchronize()
+                if int(host[0]) < k:
+                    raise RuntimeError(f"range guard: step ordinal {k} finished but its snapshot is missing (log at {int(host[0])})")
+            if int(host[1 + k % self.GUARD_RING]) != 0:
                 return self._guard_redo(0, logs)
             self._guard_pending.pop(0)
         return logs
@@ -687,7 +725,7 @@ class Model(Layer):
     def _guard_redo(self, first_bad: int, logs):
         import sys
         torch.cuda.synchronize()                             # rare: every later attempt has finished (none of them applied an update)
-        batches = [d for d, _, _ in self._guard_pending[first_bad:]]
+        batches = [p[0] for p in self._guard_pending[first_bad:]]
         self._guard_pending = []
         K.overflow_flag().zero_()
         n = len(batches)
@@ -739,6 +777,7 @@ class Model(Layer):
             if guard is not None:
                 self._dp.any_(guard)
         self.optimizer.apply_gradients(skip_flag=guard)
+        self._guard_snapshot()
         self.steps_done += 1
         return self.step_logs()
 

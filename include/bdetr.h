@@ -268,6 +268,11 @@ int bdetr_bn_stats(const float* x, int64_t rows, int C, const float* part_sum, c
  * optimizer applies nothing while it is set.  The host reads and clears it and redoes the step on the
  * exact-fp32 forward (the reference's fp32 arithmetic has no such range limit). */
 int bdetr_flag_nonfinite(const float* x, int64_t n, int* flag, void* stream);
+/* The guard word logged per step without a host synchronisation.  ordinal: one device int, advanced by each call's kernel;
+ * host_ring: 1 + ring_len ints of pinned, device-mapped HOST memory.  The kernel stores *flag at host_ring[1 + ordinal % ring_len]
+ * and then the ordinal at host_ring[0], so a host that finds host_ring[0] >= k may read step k's entry (Model._guard_poll).
+ * Capturable: it belongs to the step (the last launch of its optimizer segment), nothing is enqueued between steps. */
+int bdetr_flag_snapshot(const int* flag, int* ordinal, int* host_ring, int ring_len, void* stream);
 /* fold_ws (optional): 2*C*bdetr_bn_stats_fold_rows() floats; lets bn_stats pre-reduce thousands of
  * epilogue partial rows with a wide grid before the fp64 finalise */
 int bdetr_bn_stats_fold_rows(void);
@@ -416,12 +421,14 @@ int bdetr_match_to_mask(const int32_t* match, float* mask, int B, int M, int N, 
  *      Work is split in slabs of bdetr_sgd_slab_elems() elements; the host builds the slab
  *      table once: slab_tensor[nslabs] (owning tensor of each slab) and slab_first[ntensors+1]
  *      (first slab of each tensor), both int64 on the device.  partial: nslabs floats.
- *      lr is read from device memory (so a captured graph sees schedule updates). */
+ *      lr is read from device memory (so a captured graph sees schedule updates).
+ *      skip_flag (optional, the range guard's device int): nothing is applied while it is up, and the call itself raises it
+ *      when a tensor's gradient norm is not finite (a NaN / Inf born in the backward pass) - no tensor is then updated. */
 int bdetr_sgd_slab_elems(void);
 int bdetr_sgd_nesterov_clipnorm(const uint64_t* ptrs, const int64_t* sizes, int ntensors,
                                 const int64_t* slab_tensor, const int64_t* slab_first, int nslabs,
                                 float* partial, float* norms, const float* lr, float momentum,
-                                float clipnorm, float grad_scale, const int* skip_flag, void* stream);
+                                float clipnorm, float grad_scale, int* skip_flag, void* stream);
 
 #ifdef __cplusplus
 }

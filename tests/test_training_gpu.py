@@ -392,3 +392,66 @@ def test_graph_replayed_steps_equal_eager_steps(cuda):
     assert all(abs(a - b) <= 3e-3 * abs(a) for a, b in zip(le[:4], lg[:4])), (le, lg)
     assert all(abs(a - b) <= 5e-2 * abs(a) for a, b in zip(le, lg)), (le, lg)
     assert lg[2] != lg[4]                                                                    # fresh masks / inputs per replay, not a frozen step
+
+
+def test_unsynchronised_graph_replays_stay_finite_and_track_eager_steps(cuda):
+    """Back-to-back replays with NO host read in between (the way bench.py and a training loop without per-step logging run):
+    on ROCm 7.2 the second replay of a graph without a stream synchronisation in between handed NaN gradients to the optimizer
+    unless the runtime's pre-built-packet path is off (boosted_detr_amd/__init__.py sets DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 and
+    Model refuses graphs when that came too late).  Twelve unsynchronised steps must leave finite weights, no guard redo, and a
+    loss within the toy's run-to-run spread of the eager run."""
+    import boosted_detr_amd
+    from boosted_detr_amd import kernels as K
+    from boosted_detr_amd.engine import to_device
+    from boosted_detr_amd.training import SGD
+    from oracle import detr_oracle as O
+    assert boosted_detr_amd.graph_replay_is_safe(), "the test session initialised HIP before importing boosted_detr_amd"
+    cfg, host = small_batch()
+    params = O.make_params(cfg, seed=1)
+    batch = {"image": to_device(host["image"]), "category": to_device(host["category"], torch.int32),
+             "attribute": to_device(host["attribute"], torch.int32), "bbox": to_device(host["bbox"]),
+             "num_objects": to_device(host["num_objects"], torch.int32)}
+    final = {}
+    for graph in (False, True):
+        m = small_model()
+        m.compile(optimizer=SGD(learning_rate=1e-3, momentum=.9, nesterov=True, clipnorm=.1))
+        m.forward_backward(batch)
+        m.set_weights_dict(params)
+        m.use_graph = graph
+        for _ in range(12):
+            logs = m.train_step(batch)                 # no host read, no synchronisation between steps
+        m.guard_flush()
+        torch.cuda.synchronize()
+        assert (len(m._graphs) == 1) == graph
+        assert m.range_redos == 0 and int(K.overflow_flag().item()) == 0, (graph, m.range_redos)
+        assert all(bool(torch.isfinite(v.value).all()) for v in m.variables), graph
+        final[graph] = m.logs_to_host(logs)["loss"]
+    assert abs(final[True] - final[False]) <= 5e-2 * abs(final[False]), final
+
+
+def test_non_finite_gradient_raises_the_guard_and_applies_nothing(cuda):
+    """A NaN born in the backward pass leaves the loss finite, so the guard's loss check cannot see it: the optimizer's norm pass
+    raises the flag instead and NO tensor is updated (not even those whose own gradient is clean)."""
+    from boosted_detr_amd import kernels as K
+    from boosted_detr_amd.training import SGD
+    cfg, batch = small_batch()
+    model = small_model()
+    opt = SGD(learning_rate=0.05, momentum=0.9, nesterov=True, clipnorm=0.1)
+    model.compile(optimizer=opt)
+    model.forward_backward(batch)                      # build
+    model.forward_backward(batch)
+    tv = model.trainable_variables
+    opt.stage_gradients(tv)
+    before = [v.value.detach().clone() for v in tv]
+    opt.flat_grad[opt.flat_grad.numel() // 2] = float("nan")
+    flag = K.overflow_flag()
+    flag.zero_()
+    opt.apply_gradients(skip_flag=flag)
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 1
+    assert all(torch.equal(a, v.value) for a, v in zip(before, tv))
+    flag.zero_()
+    opt.flat_grad[opt.flat_grad.numel() // 2] = 0.0
+    opt.apply_gradients(skip_flag=flag)                # a clean gradient goes through
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 0 and any(not torch.equal(a, v.value) for a, v in zip(before, tv))
