@@ -188,11 +188,12 @@ constexpr int lds_bytes_for(int bm, int bn, int ns) { return ns * (bm + bn) * 12
 // runs.  The buffer descriptor covers exactly the tile's valid rows (rows past I are dropped by the buffer unit's range
 // check), a lane's column is valid or not for the whole tile (an invalid one starts 2 GB out of range), and the row
 // offset is one running VGPR: a store costs one add, and the second 32-column block rides the instruction's immediate.
-template <int BM, int BN, int WM, int WN>
+enum { EPI_ROWMAP = 1, EPI_ACCUM = 2, EPI_BNB = 4, EPI_ALL = 7 };
+template <int BM, int BN, int WM, int WN, bool STATS = true, int EPI = EPI_ALL>
 __device__ __forceinline__ void direct_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], const GemmParams& g, int tile_i, int i0, int j0, const float* bias_pre) {
     constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
     constexpr unsigned FAR = 0x80000000u;                    // + any in-tile offset (< 2^31) stays out of range
-    gemm_bias_act_stats<BM, BN, WM, WN>(acc, g, tile_i, i0, j0, bias_pre);
+    if constexpr (STATS) gemm_bias_act_stats<BM, BN, WM, WN>(acc, g, tile_i, i0, j0, bias_pre);      // (false: the caller already did)
     // The thread index is laundered through an empty asm: everything derived from it here is then recomputed per tile
     // (a handful of VALU ops) instead of being hoisted out of the persistent loop and held in VGPRs across the K loop,
     // where the accumulators and fragments leave no room (the hoisted copies spilled to scratch).
@@ -223,7 +224,7 @@ __device__ __forceinline__ void direct_epilogue(f32x16 (&acc)[BM / WM / 32][BN /
             for (int e = 0; e < 16; ++e) { f(a, e, ro); ro += (e & 3) == 3 ? 5u * ldc4 : ldc4; }
     };
 
-    if (g.rowmap) {
+    if constexpr ((EPI & EPI_ROWMAP) != 0) if (g.rowmap) {
         // strided scatter (1x1 stride-2 backward-data; 6 launches per step): lane l owns the row map of the wave's row l
         const __amdgpu_buffer_rsrc_t rsC = make_rsrc(g.c);
         const int i = i0 + wm * WTM + (lane % WTM);
@@ -247,7 +248,7 @@ __device__ __forceinline__ void direct_epilogue(f32x16 (&acc)[BM / WM / 32][BN /
     }
 
     const __amdgpu_buffer_rsrc_t rsC = tile_rsrc(g.c);
-    if (g.mode == ST_ACCUM) {
+    if constexpr ((EPI & EPI_ACCUM) != 0) if (g.mode == ST_ACCUM) {
         // acc_mask: the old value is a block-output gradient that still needs the unit's ReLU mask (1 bit per element:
         // element n = row * ldc + col lives in 64-bit word (n >> 8) * 4 + (n & 3), bit (n >> 2) & 63).  The masked and the
         // plain form are two complete copies (loads ... adds): with the mask loads under a run-time `if` in the middle of
@@ -289,7 +290,7 @@ __device__ __forceinline__ void direct_epilogue(f32x16 (&acc)[BM / WM / 32][BN /
         };
         if (g.acc_mask != nullptr) accumulate(std::true_type{}); else accumulate(std::false_type{});
     }
-    if (g.bnb_y != nullptr) {
+    if constexpr ((EPI & EPI_BNB) != 0) if (g.bnb_y != nullptr) {
         // fused BatchNorm-backward sums of g = C * [y' > 0] and g * xhat per column, straight from the accumulator
         // layout (a lane owns a column); one partial row per (tile_i, wm).  The ReLU decision is recomputed from y (no
         // residual) or read from the unit's bit mask (residual units); two complete copies, see the note above.
@@ -391,7 +392,11 @@ constexpr int default_occ(int bm, int bn, int wm, int wn, int ns) { return (wm *
 // K-step t from fragments already in registers, waves 4-7 read their fragments and issue their share of the LDS-DMA loads, then
 // the halves swap (see the main loop).  A wave's MFMA segment contains nothing but MFMAs and its load segment runs in the shadow
 // of its SIMD partner's MFMAs, instead of both partners stalling on the address unit at the same time.
-template <int BM, int BN, int WM, int WN, int NS, class LA, class LB, bool XX, bool F16, bool PP = false, int OCC = default_occ(BM, BN, WM, WN, NS)>
+// EPI (persistent dense kernels): which epilogue features the instantiation carries besides bias / activation / statistics and
+// plain stores - a bit set of EPI_ROWMAP (strided scatter), EPI_ACCUM (C += product, optionally masked) and EPI_BNB (fused
+// BatchNorm-backward sums).  With every variant in one kernel the variants' lane-derived invariants were hoisted over the tile
+// loop and spilled (50 VGPRs, a scratch round trip per tile: 0.19 ms against 0.12 on the 64 -> 256 channel layer at 160x160).
+template <int BM, int BN, int WM, int WN, int NS, class LA, class LB, bool XX, bool F16, bool PP = false, int OCC = default_occ(BM, BN, WM, WN, NS), int EPI = EPI_ALL>
 __global__ __launch_bounds__(WM * WN * 64, OCC)
 void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
 {
@@ -708,13 +713,16 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
                     kstep(1);
                 }
             }
-                const int e_tile_i = tile_i, e_i0 = i0, e_j0 = j0;
+            // bias / activation / statistics first (their temporaries die before the next tile's row descriptors are born), then
+            // the next tile's set-up and first stages, then the stores
+            gemm_bias_act_stats<BM, BN, WM, WN>(acc, g, tile_i, i0, j0, bias_pre);
+            const int e_tile_i = tile_i, e_i0 = i0, e_j0 = j0;
             const int nvb = vb + (int)gridDim.x;
             const bool more = nvb < total;
             if (more) { locate(nvb); setup_rows(); }
             asm volatile("s_barrier" ::: "memory");                 // every wave is done reading the ring
             if (more) prefetch();
-            direct_epilogue<BM, BN, WM, WN>(acc, g, e_tile_i, e_i0, e_j0, bias_pre);
+            direct_epilogue<BM, BN, WM, WN, false, EPI>(acc, g, e_tile_i, e_i0, e_j0, bias_pre);
             if (!more) break;
             vb = nvb;
             zero_acc();
@@ -788,6 +796,8 @@ enum { T_128x128 = 0, T_128x64 = 1, T_64x64 = 2, T_PP256x128 = 3, T_PP256x64 = 4
 const int TILE_BM[T_COUNT] = {128, 128, 64, 256, 256};
 const int TILE_BN[T_COUNT] = {128, 64, 64, 128, 64};
 const int TILE_WM[T_COUNT] = {2, 2, 2, 4, 4};
+constexpr int DENSE128_WM = 2;                                   // wave rows of the 128x128 tile in the persistent dense (1x1) kernels
+int tile_wm(int tile, bool dense) { return (dense && tile == T_128x128) ? DENSE128_WM : TILE_WM[tile]; }
 
 int forced_tile() {
     static int forced = -2;
@@ -841,12 +851,21 @@ int launch_cfg(const typename LA::Op& a, const typename LB::Op& b, GemmParams g,
         static int resident = 0;
         if (resident == 0) {
             int occ = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, sgemm_kernel<BM, BN, WM, WN, NS, LA, LB, XX, F16, PP, OCC>, WM * WN * 64, 0) != hipSuccess || occ < 1) occ = 1;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, sgemm_kernel<BM, BN, WM, WN, NS, LA, LB, XX, F16, PP, OCC, EPI_ALL>, WM * WN * 64, 0) != hipSuccess || occ < 1) occ = 1;
             resident = occ * num_cus() / 8 * 8;
             if (resident < 8) resident = 8;
         }
         BDETR_CHECK_ARG(zdim == 1 && g.splitk == 1, "sgemm: the persistent kernels take no split-K / batch dimension");
         if ((int)grid.x > resident) grid.x = resident;
+        const int need = (g.rowmap ? EPI_ROWMAP : 0) | (g.mode == ST_ACCUM ? EPI_ACCUM : 0) | (g.bnb_y != nullptr ? EPI_BNB : 0);
+        auto go = [&](auto epi_c) {
+            hipLaunchKernelGGL((sgemm_kernel<BM, BN, WM, WN, NS, LA, LB, XX, F16, PP, OCC, decltype(epi_c)::value>), grid, dim3(WM * WN * 64), 0, st, a, b, g);
+            if (prof) prof_end(st);
+            return bdetr_launch_status("sgemm");
+        };
+        if (need == 0) return go(std::integral_constant<int, 0>{});                                  // (see EPI)
+        if (need == EPI_BNB) return go(std::integral_constant<int, EPI_BNB>{});
+        if ((need & EPI_ROWMAP) == 0) return go(std::integral_constant<int, EPI_ACCUM | EPI_BNB>{});
     }
     hipLaunchKernelGGL((sgemm_kernel<BM, BN, WM, WN, NS, LA, LB, XX, F16, PP, OCC>), grid, dim3(WM * WN * 64), 0, st, a, b, g);
     if (prof) prof_end(st);
@@ -856,7 +875,12 @@ int launch_cfg(const typename LA::Op& a, const typename LB::Op& b, GemmParams g,
 template <class LA, class LB, bool XX, bool F16>
 int launch_any(const typename LA::Op& a, const typename LB::Op& b, const GemmParams& g, int zdim, hipStream_t st, int kind, int tile) {
     switch (tile) {
-        case T_128x128:    return launch_cfg<128, 128, 2, 2, 2, LA, LB, XX, F16>(a, b, g, zdim, st, kind);
+        case T_128x128:
+            // (DENSE128_WM = 4: the persistent dense kernels on EIGHT waves - wave tile 32x64, 4 waves per SIMD at two workgroups per
+            // CU, 127 VGPRs without spills in the plain-epilogue flavour.  Measured equal or slower than four waves on every 1x1
+            // layer and 1.3 % slower on the step, round 3; kept as a switch.)
+            if constexpr (!XX && std::is_same_v<LA, RRDense> && DENSE128_WM == 4) return launch_cfg<128, 128, 4, 2, 2, LA, LB, XX, F16, false, 4>(a, b, g, zdim, st, kind);
+            else return launch_cfg<128, 128, 2, 2, 2, LA, LB, XX, F16>(a, b, g, zdim, st, kind);
         case T_128x64:     return launch_cfg<128, 64, 2, 2, 2, LA, LB, XX, F16>(a, b, g, zdim, st, kind);
         case T_PP256x128:
             // (the f16 flavour keeps two accumulator sets: with the fragments of a whole K-step resident it does not fit 256 VGPRs)
@@ -936,7 +960,7 @@ extern "C" int bdetr_p16_conv2d_fwd_stat_chunks(const bdetr_conv_desc* d) {
     if (check_conv(d, "bdetr_p16_conv2d_fwd_stat_chunks")) return -1;
     if (const int ht = fwd_hconv(d)) return (int)cdiv64((int64_t)d->N * d->OH * d->OW, ht / 1000) * 4;      // tiles_i * WM (4 wave rows)
     const int t = fwd_tile(d);
-    return (int)cdiv64((int64_t)d->N * d->OH * d->OW, TILE_BM[t]) * TILE_WM[t];          // tiles_i * WM
+    return (int)cdiv64((int64_t)d->N * d->OH * d->OW, TILE_BM[t]) * tile_wm(t, is_1x1_dense(d));          // tiles_i * WM
 }
 
 extern "C" int bdetr_p16_conv2d_fwd(const void* x_f16, const void* w_f16, const float* bias, float* y,
@@ -980,7 +1004,7 @@ extern "C" int bdetr_p16_conv2d_bwd_data_stat_chunks(const bdetr_conv_desc* d) {
     if (const int ht = bwd_data_hconv(d)) return (int)cdiv64((int64_t)d->N * d->H * d->W, ht / 1000);      // one partial row per tile_i
     const int t = bwd_data_tile(d);
     // the persistent dense kernels write one partial row per (tile_i, wave row), the patch kernels one per tile_i
-    return (int)cdiv64(dense ? (int64_t)d->N * d->OH * d->OW : (int64_t)d->N * d->H * d->W, TILE_BM[t]) * (dense ? TILE_WM[t] : 1);
+    return (int)cdiv64(dense ? (int64_t)d->N * d->OH * d->OW : (int64_t)d->N * d->H * d->W, TILE_BM[t]) * (dense ? tile_wm(t, true) : 1);
 }
 
 // dy_bf16: P16-bf16 [N,OH,OW,K]; wt_bf16: the transposed / tap-flipped P16-bf16 weight copy [C][R*S][K]

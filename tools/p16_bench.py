@@ -56,6 +56,9 @@ with k.gemm_precision("split"):
         for i in range(3):
             tot["old"][i] += mult * t_old[i]; tot["p16"][i] += mult * t_new[i]
         f = lambda ts: " ".join(f"{t:6.3f}({gf / t:5.0f})" for t in ts)
-        print(f"{H:3d}x{H:<3d} C{Cc:<4d} K{K_:<4d} {R}x{R} s{s} x{mult:<2d}     {gf:7.1f} | {f(t_old)} | {f(t_new)}", flush=True)
+        # HBM floor of one pass: both activation tensors once at 4 bytes per element (P16 pair in, fp32 out), at the 6.3 TB/s a copy reaches
+        hbm_ms = (B * H * H * Cc + g.M * K_) * 4 / 6.3e12 * 1e3
+        print(f"{H:3d}x{H:<3d} C{Cc:<4d} K{K_:<4d} {R}x{R} s{s} x{mult:<2d}     {gf:7.1f} | {f(t_old)} | {f(t_new)} | hbm floor {hbm_ms:6.3f} ms, fwd/dgrad/wgrad at "
+              + "/".join(f"{hbm_ms / t:4.2f}" for t in t_new), flush=True)
 print("per step (weighted by multiplicity): old fwd %.2f dgrad %.2f wgrad %.2f = %.2f ms | p16 fwd %.2f dgrad %.2f wgrad %.2f = %.2f ms"
       % (*tot["old"], sum(tot["old"]), *tot["p16"], sum(tot["p16"])))
