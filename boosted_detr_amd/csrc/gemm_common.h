@@ -34,8 +34,8 @@ struct GemmParams {
     // that would re-read C and y (colreduce2<BnBwdFn>) disappears.  bnb_y has C's shape and leading dimension.
     const float* bnb_y; const float* bnb_mean; const float* bnb_rstd; const float* bnb_gamma; const float* bnb_beta;
     int bnb_relu; float* bnb_sum_g; float* bnb_sum_gx;
-    const unsigned long long* bnb_mask;      // (sgemm's persistent dense kernels) the ReLU decision comes from these bits, not from recomputing it
-    // ST_ACCUM with acc_mask set (sgemm's persistent dense kernels only): C = product + C * bit, bit = bn_apply_p16's 1-bit
+    const unsigned long long* bnb_mask;      // (sgemm's dense 1x1 kernels, with acc_mask) the ReLU decision comes from these bits, not from recomputing it
+    // ST_ACCUM with acc_mask set (sgemm's dense 1x1 kernels only): C = product + C * bit, bit = bn_apply_p16's 1-bit
     // ReLU mask of the element (norm.hip relu_mask_bits4 layout) - the skip branch of a residual unit merged without ever
     // materialising its masked gradient
     const unsigned long long* acc_mask;
@@ -130,12 +130,19 @@ __device__ __forceinline__ void gemm_bias_act_stats(f32x16 (&acc)[BM / WM / 32][
     else bias_act_stats(std::integral_constant<int, BDETR_ACT_TANH>{});
 }
 
+// bn_apply_p16's ReLU bit mask (norm.hip relu_mask_bits4): component e of float4 index i lives in 64-bit word (i >> 6) * 4 + e, bit i & 63
+__device__ __forceinline__ unsigned mask_bits4(const unsigned long long* mask, int64_t i) {
+    const unsigned long long* w = mask + (i >> 6) * 4;
+    const int b = (int)(i & 63);
+    return (unsigned)((w[0] >> b) & 1ull) | ((unsigned)((w[1] >> b) & 1ull) << 1) | ((unsigned)((w[2] >> b) & 1ull) << 2) | ((unsigned)((w[3] >> b) & 1ull) << 3);
+}
+
 // Epilogue of a BM x BN workgroup tile held as TM x TN 32x32 accumulators per wave (C/D layout of the
 // 32x32 MFMAs: column = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)): bias + activation and the
 // statistics (above), then either LDS-transposed 16-byte row stores (store / accumulate) or per-element stores /
 // atomics (split-K).  `lds` must hold LDS_FLOATS >= BM * BN floats and be free to overwrite once every wave has
 // passed the barrier this function starts with.
-template <int BM, int BN, int WM, int WN, int NT, int LDS_FLOATS>
+template <int BM, int BN, int WM, int WN, int NT, int LDS_FLOATS, bool MASKED_VARIANTS = false>
 __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], const GemmParams& g, float* lds,
                                               int tile_i, int i0, int j0, float* cbase, const float* bias_pre = nullptr) {
     constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
@@ -178,50 +185,73 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
         // Every uniform switch (row map, accumulate, fused BatchNorm-backward sums) selects a fully unrolled copy of the
         // loop: all LDS reads, then all global loads, then the stores - one memory round trip per tile instead of one
         // per row group (the run-time switches inside a rolled loop waited on every load and store in turn).
-        auto vec_out = [&](auto rowmap_c, auto accum_c, auto bnb_c) {
-            constexpr bool ROWMAP = decltype(rowmap_c)::value, ACCUM = decltype(accum_c)::value, BNB = decltype(bnb_c)::value;
-            f32x4 val[ITERS], old[ACCUM ? ITERS : 1], yv[BNB ? ITERS : 1];
-            float* dst[ITERS];
-            bool ok[ITERS];
-#pragma unroll
-            for (int it = 0; it < ITERS; ++it) val[it] = *reinterpret_cast<const f32x4*>(lrow + it * RSTEP * CLD);
-#pragma unroll
-            for (int it = 0; it < ITERS; ++it) {
-                const int i = i0 + r0 + it * RSTEP;
-                ok[it] = jok && i < g.I;
-                int64_t row = i;
-                if constexpr (ROWMAP) row = out_row(i);
-                dst[it] = cbase + row * g.ldc + jc;
-                if constexpr (ACCUM) { old[it] = f32x4{0, 0, 0, 0}; if (ok[it]) old[it] = *reinterpret_cast<const f32x4*>(dst[it]); }
-                if constexpr (BNB) { yv[it] = f32x4{0, 0, 0, 0}; if (ok[it]) yv[it] = *reinterpret_cast<const f32x4*>(g.bnb_y + (int64_t)i * g.ldc + jc); }
-            }
-#pragma unroll
-            for (int it = 0; it < ITERS; ++it) {
-                if constexpr (ACCUM) val[it] += old[it];
-                if (BDETR_DBG(g, 1) && val[it][0] != 1234567.f) continue;
-                if (ok[it]) *reinterpret_cast<f32x4*>(dst[it]) = val[it];
-            }
+        // MASKED (1x1 stride-1 backward-data of a residual unit's first convolution): the old value is the unit's output gradient
+        // still without its ReLU mask - C = product + old * bit (g.acc_mask) - and, with BNB, the ReLU decision of the fused sums
+        // comes from g.bnb_mask instead of being recomputed.  Accumulate + sums together keep three float4 per row group alive
+        // (product, old, y): that combination runs the tile in two halves so that it stays inside 256 VGPRs.
+        auto vec_out = [&](auto rowmap_c, auto accum_c, auto bnb_c, auto masked_c) {
+            constexpr bool ROWMAP = decltype(rowmap_c)::value, ACCUM = decltype(accum_c)::value, BNB = decltype(bnb_c)::value, MASKED = decltype(masked_c)::value;
+            constexpr int NPART = (ACCUM && BNB) ? 2 : 1, PIT = ITERS / NPART;
+            static_assert(ITERS % NPART == 0, "the tile splits into equal parts");
+            f32x4 bnv[BNB ? 6 : 1];                       // mean, rstd, gamma, beta of the thread's 4 columns; running sums of g, g * xhat
             if constexpr (BNB) {
-                f32x4 bm = {0, 0, 0, 0}, brs = bm, bgm = bm, bbt = bm, sg = bm, sgx = bm;
+#pragma unroll
+                for (int q = 0; q < 6; ++q) bnv[q] = f32x4{0, 0, 0, 0};
                 if (jok) {
-                    bm = *reinterpret_cast<const f32x4*>(g.bnb_mean + jc); brs = *reinterpret_cast<const f32x4*>(g.bnb_rstd + jc);
-                    bgm = *reinterpret_cast<const f32x4*>(g.bnb_gamma + jc); bbt = *reinterpret_cast<const f32x4*>(g.bnb_beta + jc);
+                    bnv[0] = *reinterpret_cast<const f32x4*>(g.bnb_mean + jc); bnv[1] = *reinterpret_cast<const f32x4*>(g.bnb_rstd + jc);
+                    bnv[2] = *reinterpret_cast<const f32x4*>(g.bnb_gamma + jc); bnv[3] = *reinterpret_cast<const f32x4*>(g.bnb_beta + jc);
+                }
+            }
+#pragma unroll
+            for (int part = 0; part < NPART; ++part) {
+                f32x4 val[PIT], old[ACCUM ? PIT : 1], yv[BNB ? PIT : 1];
+                unsigned abits[(ACCUM && MASKED) ? PIT : 1], bbits[(BNB && MASKED) ? PIT : 1];
+                float* dst[PIT];
+                bool ok[PIT];
+#pragma unroll
+                for (int k = 0; k < PIT; ++k) val[k] = *reinterpret_cast<const f32x4*>(lrow + (part * PIT + k) * RSTEP * CLD);
+#pragma unroll
+                for (int k = 0; k < PIT; ++k) {
+                    const int i = i0 + r0 + (part * PIT + k) * RSTEP;
+                    ok[k] = jok && i < g.I;
+                    int64_t row = i;
+                    if constexpr (ROWMAP) row = out_row(i);
+                    dst[k] = cbase + row * g.ldc + jc;
+                    if constexpr (ACCUM) { old[k] = f32x4{0, 0, 0, 0}; if (ok[k]) old[k] = *reinterpret_cast<const f32x4*>(dst[k]); }
+                    if constexpr (ACCUM && MASKED) { abits[k] = 0u; if (ok[k]) abits[k] = mask_bits4(g.acc_mask, (row * g.ldc + jc) >> 2); }
+                    if constexpr (BNB) { yv[k] = f32x4{0, 0, 0, 0}; if (ok[k]) yv[k] = *reinterpret_cast<const f32x4*>(g.bnb_y + (int64_t)i * g.ldc + jc); }
+                    if constexpr (BNB && MASKED) { bbits[k] = 0u; if (ok[k]) bbits[k] = mask_bits4(g.bnb_mask, ((int64_t)i * g.ldc + jc) >> 2); }
                 }
 #pragma unroll
-                for (int it = 0; it < ITERS; ++it) {
-                    if (!ok[it]) continue;
+                for (int k = 0; k < PIT; ++k) {
+                    if constexpr (ACCUM && MASKED) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const bool on = !g.bnb_relu || (__builtin_fmaf(yv[it][e] - bm[e], brs[e] * bgm[e], bbt[e]) > 0.f);      // = norm.hip's bn_affine
-                        const float ge = on ? val[it][e] : 0.f;
-                        sg[e] += ge; sgx[e] += ge * ((yv[it][e] - bm[e]) * brs[e]);
+                        for (int e = 0; e < 4; ++e) val[k][e] += ((abits[k] >> e) & 1u) ? old[k][e] : 0.f;
+                    } else if constexpr (ACCUM) val[k] += old[k];
+                    if (BDETR_DBG(g, 1) && val[k][0] != 1234567.f) continue;
+                    if (ok[k]) *reinterpret_cast<f32x4*>(dst[k]) = val[k];
+                }
+                if constexpr (BNB) {
+#pragma unroll
+                    for (int k = 0; k < PIT; ++k) {
+                        if (!ok[k]) continue;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            bool on;
+                            if constexpr (MASKED) on = ((bbits[k] >> e) & 1u) != 0u;
+                            else on = !g.bnb_relu || (__builtin_fmaf(yv[k][e] - bnv[0][e], bnv[1][e] * bnv[2][e], bnv[3][e]) > 0.f);      // = norm.hip's bn_affine
+                            const float ge = on ? val[k][e] : 0.f;
+                            bnv[4][e] += ge; bnv[5][e] += ge * ((yv[k][e] - bnv[0][e]) * bnv[1][e]);
+                        }
                     }
                 }
+            }
+            if constexpr (BNB) {
                 // fold the NT / V_PER_ROW threads that share a column group (fixed order), one partial row per tile_i
                 static_assert(NT * 8 <= LDS_FLOATS, "reduction scratch must fit");
                 __syncthreads();                                      // every thread is done reading the C tile
-                *reinterpret_cast<f32x4*>(lds + tid * 8) = sg;
-                *reinterpret_cast<f32x4*>(lds + tid * 8 + 4) = sgx;
+                *reinterpret_cast<f32x4*>(lds + tid * 8) = bnv[4];
+                *reinterpret_cast<f32x4*>(lds + tid * 8 + 4) = bnv[5];
                 __syncthreads();
                 if (tid < V_PER_ROW && jok) {
                     f32x4 a = {0, 0, 0, 0}, b = a;
@@ -237,10 +267,17 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
         };
         using T = std::true_type; using F = std::false_type;
         const bool accum = g.mode == ST_ACCUM;
-        if (g.bnb_y != nullptr) vec_out(F{}, F{}, T{});                      // host contract: plain store, no row map
-        else if (g.rowmap) { if (accum) vec_out(T{}, T{}, F{}); else vec_out(T{}, F{}, F{}); }
-        else if (accum) vec_out(F{}, T{}, F{});
-        else vec_out(F{}, F{}, F{});
+        // host contracts: fused sums never come with a row map; a masked accumulate comes with masked sums or with none
+        if constexpr (MASKED_VARIANTS) {
+            if (g.acc_mask != nullptr) {
+                if (g.bnb_y != nullptr) vec_out(F{}, T{}, T{}, T{}); else vec_out(F{}, T{}, F{}, T{});
+                return;
+            }
+        }
+        if (g.bnb_y != nullptr) vec_out(F{}, F{}, T{}, F{});
+        else if (g.rowmap) { if (accum) vec_out(T{}, T{}, F{}, F{}); else vec_out(T{}, F{}, F{}, F{}); }
+        else if (accum) vec_out(F{}, T{}, F{}, F{});
+        else vec_out(F{}, F{}, F{}, F{});
         return;
     }
     // per-element stores / accumulates / atomics (split-K, or rows that are not 16-byte aligned): the mode is hoisted too

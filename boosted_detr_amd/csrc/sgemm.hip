@@ -188,8 +188,8 @@ constexpr int lds_bytes_for(int bm, int bn, int ns) { return ns * (bm + bn) * 12
 // runs.  The buffer descriptor covers exactly the tile's valid rows (rows past I are dropped by the buffer unit's range
 // check), a lane's column is valid or not for the whole tile (an invalid one starts 2 GB out of range), and the row
 // offset is one running VGPR: a store costs one add, and the second 32-column block rides the instruction's immediate.
-enum { EPI_ROWMAP = 1, EPI_ACCUM = 2, EPI_BNB = 4, EPI_ALL = 7 };
-template <int BM, int BN, int WM, int WN, bool STATS = true, int EPI = EPI_ALL>
+enum { EPI_PLAIN = 0, EPI_ROWMAP = 1, EPI_VEC = 8 };
+template <int BM, int BN, int WM, int WN, bool STATS = true, int EPI = EPI_ROWMAP>
 __device__ __forceinline__ void direct_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], const GemmParams& g, int tile_i, int i0, int j0, const float* bias_pre) {
     constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
     constexpr unsigned FAR = 0x80000000u;                    // + any in-tile offset (< 2^31) stays out of range
@@ -248,96 +248,6 @@ __device__ __forceinline__ void direct_epilogue(f32x16 (&acc)[BM / WM / 32][BN /
     }
 
     const __amdgpu_buffer_rsrc_t rsC = tile_rsrc(g.c);
-    if constexpr ((EPI & EPI_ACCUM) != 0) if (g.mode == ST_ACCUM) {
-        // acc_mask: the old value is a block-output gradient that still needs the unit's ReLU mask (1 bit per element:
-        // element n = row * ldc + col lives in 64-bit word (n >> 8) * 4 + (n & 3), bit (n >> 2) & 63).  The masked and the
-        // plain form are two complete copies (loads ... adds): with the mask loads under a run-time `if` in the middle of
-        // one copy, a few of the plain form's old values were consumed before they had landed (sporadic 64-byte runs of
-        // the C tile came out as product + 0).
-        auto accumulate = [&](auto masked_c) {
-            constexpr bool MASKED = decltype(masked_c)::value;
-            const __amdgpu_buffer_rsrc_t rsM = make_rsrc(g.acc_mask, MASKED ? (unsigned)(((int64_t)g.I * g.ldc + 255) >> 8) * 32u : 0u);   // exactly the mask: rows past I read as 0
-#pragma unroll
-            for (int a = 0; a < TM; ++a) {
-                float old[TN][16];
-                unsigned keep[TN];
-#pragma unroll
-                for (int b = 0; b < TN; ++b) keep[b] = 0u;
-                unsigned ro = (unsigned)(a * 32) * ldc4;
-                unsigned nrow = (unsigned)(i0 + wm * WTM + 4 * lh + a * 32) * (unsigned)g.ldc + (unsigned)jl;      // element index of (e = 0, b = 0)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-#pragma unroll
-                    for (int b = 0; b < TN; ++b) {
-                        old[b][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsC, vcol[b] + ro, 0, 0));
-                        if constexpr (MASKED) {
-                            const unsigned n = nrow + 32u * b;
-                            const unsigned wo = vcol[b] == FAR ? OOB : ((((n >> 8) << 2) | (n & 3u)) << 3) + ((n >> 5) & 4u);     // the dword holding bit (n >> 2) & 63
-                            keep[b] |= ((__builtin_amdgcn_raw_buffer_load_b32(rsM, wo, 0, 0) >> ((n >> 2) & 31u)) & 1u) << e;
-                        }
-                    }
-                    ro += (e & 3) == 3 ? 5u * ldc4 : ldc4;
-                    nrow += ((e & 3) == 3 ? 5u : 1u) * (unsigned)g.ldc;
-                }
-#pragma unroll
-                for (int b = 0; b < TN; ++b)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        if constexpr (MASKED) acc[a][b][e] += ((keep[b] >> e) & 1u) ? old[b][e] : 0.f;
-                        else acc[a][b][e] += old[b][e];
-                    }
-            }
-        };
-        if (g.acc_mask != nullptr) accumulate(std::true_type{}); else accumulate(std::false_type{});
-    }
-    if constexpr ((EPI & EPI_BNB) != 0) if (g.bnb_y != nullptr) {
-        // fused BatchNorm-backward sums of g = C * [y' > 0] and g * xhat per column, straight from the accumulator
-        // layout (a lane owns a column); one partial row per (tile_i, wm).  The ReLU decision is recomputed from y (no
-        // residual) or read from the unit's bit mask (residual units); two complete copies, see the note above.
-        auto bn_sums = [&](auto bits_c) {
-            constexpr bool BITS = decltype(bits_c)::value;
-            const __amdgpu_buffer_rsrc_t rsY = tile_rsrc(g.bnb_y);
-            const __amdgpu_buffer_rsrc_t rsB = make_rsrc(g.bnb_mask, BITS ? (unsigned)(((int64_t)g.I * g.ldc + 255) >> 8) * 32u : 0u);
-#pragma unroll
-            for (int b = 0; b < TN; ++b) {
-                const int j = jl + b * 32;
-                const bool jok = j < g.J;
-                const float bm = jok ? g.bnb_mean[j] : 0.f, brs = jok ? g.bnb_rstd[j] : 0.f, bgm = jok ? g.bnb_gamma[j] : 0.f, bbt = jok ? g.bnb_beta[j] : 0.f;
-                float yv[TM][16];
-                unsigned keep[TM];                        // bit e = the ReLU decision of accumulator register e of block (a, b)
-#pragma unroll
-                for (int a = 0; a < TM; ++a) keep[a] = 0u;
-                for_rows([&](int a, int e, unsigned ro) {
-                    yv[a][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsY, vcol[b] + ro, 0, 0));
-                    if constexpr (BITS) {
-                        const unsigned n = (unsigned)(i0 + wm * WTM + 4 * lh + a * 32 + (e & 3) + 8 * (e >> 2)) * (unsigned)g.ldc + (unsigned)j;
-                        const unsigned wo = vcol[b] == FAR ? OOB : ((((n >> 8) << 2) | (n & 3u)) << 3) + ((n >> 5) & 4u);
-                        keep[a] |= ((__builtin_amdgcn_raw_buffer_load_b32(rsB, wo, 0, 0) >> ((n >> 2) & 31u)) & 1u) << e;
-                    }
-                });
-                float sg = 0.f, sgx = 0.f;
-#pragma unroll
-                for (int a = 0; a < TM; ++a)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const bool in = wm * WTM + 4 * lh + a * 32 + (e & 3) + 8 * (e >> 2) < rows_here;
-                        bool on;
-                        if constexpr (BITS) on = in && ((keep[a] >> e) & 1u) != 0u;
-                        else on = in && (!g.bnb_relu || (__builtin_fmaf(yv[a][e] - bm, brs * bgm, bbt) > 0.f));      // = norm.hip's bn_affine
-                        const float ge = on ? acc[a][b][e] : 0.f;
-                        sg += ge; sgx += ge * ((yv[a][e] - bm) * brs);
-                    }
-                sg += __shfl_xor(sg, 32, 64);
-                sgx += __shfl_xor(sgx, 32, 64);
-                if (lh == 0 && jok) {
-                    const int64_t chunk = (int64_t)tile_i * WM + wm;
-                    g.bnb_sum_g[chunk * g.J + j] = sg;
-                    g.bnb_sum_gx[chunk * g.J + j] = sgx;
-                }
-            }
-        };
-        if (g.bnb_mask != nullptr) bn_sums(std::true_type{}); else bn_sums(std::false_type{});
-    }
     if (BDETR_DBG(g, 1)) return;
     for_rows([&](int a, int e, unsigned ro) {
 #pragma unroll
@@ -392,11 +302,14 @@ constexpr int default_occ(int bm, int bn, int wm, int wn, int ns) { return (wm *
 // K-step t from fragments already in registers, waves 4-7 read their fragments and issue their share of the LDS-DMA loads, then
 // the halves swap (see the main loop).  A wave's MFMA segment contains nothing but MFMAs and its load segment runs in the shadow
 // of its SIMD partner's MFMAs, instead of both partners stalling on the address unit at the same time.
-// EPI (persistent dense kernels): which epilogue features the instantiation carries besides bias / activation / statistics and
-// plain stores - a bit set of EPI_ROWMAP (strided scatter), EPI_ACCUM (C += product, optionally masked) and EPI_BNB (fused
-// BatchNorm-backward sums).  With every variant in one kernel the variants' lane-derived invariants were hoisted over the tile
-// loop and spilled (50 VGPRs, a scratch round trip per tile: 0.19 ms against 0.12 on the 64 -> 256 channel layer at 160x160).
-template <int BM, int BN, int WM, int WN, int NS, class LA, class LB, bool XX, bool F16, bool PP = false, int OCC = default_occ(BM, BN, WM, WN, NS), int EPI = EPI_ALL>
+// EPI (dense 1x1 kernels): EPI_PLAIN = persistent, register epilogue with bias / activation / statistics and plain stores only;
+// EPI_ROWMAP = persistent, plus the strided scatter (with or without accumulate) of the stride-2 backward-data launches;
+// EPI_VEC = NOT persistent, LDS-transposed float4 epilogue (gemm_epilogue) with its accumulate / masked accumulate / fused
+// BatchNorm-backward-sum variants.  With every variant in the persistent kernel the variants' lane-derived invariants were hoisted
+// over the tile loop and spilled (50 VGPRs, a scratch round trip per tile: 0.19 ms against 0.12 on the 64 -> 256 channel layer at
+// 160x160), and the register epilogue's accumulate / sums - one dword per lane, up to 3 x 64 loads per lane and tile - ran at a
+// third of their HBM floor (tools/dgrad_epi_probe.py).
+template <int BM, int BN, int WM, int WN, int NS, class LA, class LB, bool XX, bool F16, bool PP = false, int OCC = default_occ(BM, BN, WM, WN, NS), int EPI = EPI_ROWMAP>
 __global__ __launch_bounds__(WM * WN * 64, OCC)
 void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
 {
@@ -428,7 +341,7 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
     // MFMA-bound, measured equal or slower when persistent, and the f16 128x128 one does not fit its accumulators plus
     // the loop-carried state in 256 VGPRs) and the XX kernels (split-K weight gradients) run one virtual block per
     // workgroup.
-    constexpr bool PERSIST = !PP && !XX && std::is_same_v<LA, RRDense>;
+    constexpr bool PERSIST = !PP && !XX && std::is_same_v<LA, RRDense> && (EPI & EPI_VEC) == 0;
     static_assert(PP ? (NS == 3 && NW == 8) : NS == 2, "the plain loops are written for a two-stage ring, the ping-pong loop for three stages and 8 waves");
     const int nwg = g.tiles_i * g.tiles_j;
     const int total = PERSIST ? nwg : nwg * (int)gridDim.z;
@@ -774,7 +687,7 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
             atomic_epilogue<BM, BN, WM, WN>(acc, g, i0, j0);
             return;
         }
-        gemm_epilogue<BM, BN, WM, WN, NT, LDS_BYTES / 4>(acc, g, reinterpret_cast<float*>(lds), tile_i, i0, j0, g.c, bias_pre);
+        gemm_epilogue<BM, BN, WM, WN, NT, LDS_BYTES / 4, (EPI & EPI_VEC) != 0>(acc, g, reinterpret_cast<float*>(lds), tile_i, i0, j0, g.c, bias_pre);
     }
 }
 
@@ -847,25 +760,30 @@ int launch_cfg(const typename LA::Op& a, const typename LB::Op& b, GemmParams g,
     if (prof) prof_begin(st, 2.0 * (double)g.I * (double)g.J * (double)g.R, g.I, g.J, g.R, zdim, BM, BN * 10 + NS,
                          (F16 ? AR_P16_F16 : AR_P16_BF16) * 10000 + kind);
     if constexpr (!PP && !XX && std::is_same_v<LA, RRDense>) {
-        // persistent: as many workgroups as stay resident (a multiple of 8: one XCD per workgroup for all its tiles)
-        static int resident = 0;
-        if (resident == 0) {
-            int occ = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, sgemm_kernel<BM, BN, WM, WN, NS, LA, LB, XX, F16, PP, OCC, EPI_ALL>, WM * WN * 64, 0) != hipSuccess || occ < 1) occ = 1;
-            resident = occ * num_cus() / 8 * 8;
-            if (resident < 8) resident = 8;
-        }
-        BDETR_CHECK_ARG(zdim == 1 && g.splitk == 1, "sgemm: the persistent kernels take no split-K / batch dimension");
-        if ((int)grid.x > resident) grid.x = resident;
-        const int need = (g.rowmap ? EPI_ROWMAP : 0) | (g.mode == ST_ACCUM ? EPI_ACCUM : 0) | (g.bnb_y != nullptr ? EPI_BNB : 0);
         auto go = [&](auto epi_c) {
             hipLaunchKernelGGL((sgemm_kernel<BM, BN, WM, WN, NS, LA, LB, XX, F16, PP, OCC, decltype(epi_c)::value>), grid, dim3(WM * WN * 64), 0, st, a, b, g);
             if (prof) prof_end(st);
             return bdetr_launch_status("sgemm");
         };
-        if (need == 0) return go(std::integral_constant<int, 0>{});                                  // (see EPI)
-        if (need == EPI_BNB) return go(std::integral_constant<int, EPI_BNB>{});
-        if ((need & EPI_ROWMAP) == 0) return go(std::integral_constant<int, EPI_ACCUM | EPI_BNB>{});
+        BDETR_CHECK_ARG(zdim == 1 && g.splitk == 1, "sgemm: the dense 1x1 kernels take no split-K / batch dimension");
+        if (!g.rowmap && (g.mode == ST_ACCUM || g.bnb_y != nullptr)) {        // accumulate / fused sums: one workgroup per tile, float4 epilogue (see EPI)
+            BDETR_CHECK_ARG(g.vec_store, "sgemm: accumulate / fused BatchNorm-backward sums need 16-byte aligned C rows and J %% 4 == 0");
+            BDETR_CHECK_ARG(g.acc_mask == nullptr || g.mode == ST_ACCUM, "sgemm: acc_mask without accumulate");
+            BDETR_CHECK_ARG(g.bnb_mask == nullptr || (g.acc_mask != nullptr && g.bnb_y != nullptr), "sgemm: a bit-mask ReLU decision comes with a masked accumulate");
+            return go(std::integral_constant<int, EPI_VEC>{});
+        }
+        BDETR_CHECK_ARG(g.acc_mask == nullptr && g.bnb_y == nullptr, "sgemm: masks / fused sums are not available with a row map");
+        // persistent: as many workgroups as stay resident (a multiple of 8: one XCD per workgroup for all its tiles)
+        static int resident = 0;
+        if (resident == 0) {
+            int occ = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, sgemm_kernel<BM, BN, WM, WN, NS, LA, LB, XX, F16, PP, OCC, EPI_ROWMAP>, WM * WN * 64, 0) != hipSuccess || occ < 1) occ = 1;
+            resident = occ * num_cus() / 8 * 8;
+            if (resident < 8) resident = 8;
+        }
+        if ((int)grid.x > resident) grid.x = resident;
+        if (!g.rowmap) return go(std::integral_constant<int, EPI_PLAIN>{});
+        return go(std::integral_constant<int, EPI_ROWMAP>{});
     }
     hipLaunchKernelGGL((sgemm_kernel<BM, BN, WM, WN, NS, LA, LB, XX, F16, PP, OCC>), grid, dim3(WM * WN * 64), 0, st, a, b, g);
     if (prof) prof_end(st);
@@ -1003,8 +921,8 @@ extern "C" int bdetr_p16_conv2d_bwd_data_stat_chunks(const bdetr_conv_desc* d) {
     const bool dense = d->R == 1 && d->S == 1 && d->pad == 0;
     if (const int ht = bwd_data_hconv(d)) return (int)cdiv64((int64_t)d->N * d->H * d->W, ht / 1000);      // one partial row per tile_i
     const int t = bwd_data_tile(d);
-    // the persistent dense kernels write one partial row per (tile_i, wave row), the patch kernels one per tile_i
-    return (int)cdiv64(dense ? (int64_t)d->N * d->OH * d->OW : (int64_t)d->N * d->H * d->W, TILE_BM[t]) * (dense ? tile_wm(t, true) : 1);
+    // one partial row per tile_i (the LDS-transposed epilogue folds the tile's rows)
+    return (int)cdiv64(dense ? (int64_t)d->N * d->OH * d->OW : (int64_t)d->N * d->H * d->W, TILE_BM[t]);
 }
 
 // dy_bf16: P16-bf16 [N,OH,OW,K]; wt_bf16: the transposed / tap-flipped P16-bf16 weight copy [C][R*S][K]
