@@ -125,7 +125,7 @@ def hbm_traffic_per_launch():
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 d = json.load(f)
-            return round(d["hbm_bytes_per_launch"]), {"file": f"profiles/{name}", "profiled_commit": d.get("commit"), "steps": d.get("steps")}
+            return round(d["hbm_bytes_per_launch"]), {"file": f"profiles/{name}", "profiled_commit": d.get("profiled_commit") or d.get("commit"), "steps": d.get("steps") or d.get("steps_in_trace")}
         except Exception:
             continue
     return None, None

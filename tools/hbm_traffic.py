@@ -1,10 +1,11 @@
 """Turn two rocprofv3 PMC passes (--pmc FETCH_SIZE and --pmc WRITE_SIZE, each with --kernel-trace, CSV output)
-into HBM bytes per GEMM-family launch (igemm_kernel + sgemm_kernel), per step, and per kernel name, with the gfx950
+into HBM bytes per GEMM-family launch (igemm_kernel + sgemm_kernel + hconv_kernel), per step, and per kernel name, with the gfx950
 corrections of MI355X_MICROARCH.md (FETCH_SIZE counts 128-B requests at 64 B -> x2; both counters are in KB).
 
 usage: python tools/hbm_traffic.py <fetch_dir> <write_dir> <steps_in_trace> <out.json> [kernel_stats.csv <steps_in_stats_trace>]
 With the optional kernel-stats CSV (rocprofv3 --kernel-trace --stats of the same command) every kernel also gets its
-average HBM rate = bytes per step / time per step."""
+average HBM rate = bytes per step / time per step.  BDETR_COMMIT (the commit the snapshot was taken from; the GPU box has no .git)
+is recorded as `profiled_commit`."""
 import csv, glob, json, os, re, sys
 
 
@@ -28,7 +29,7 @@ def short(name):
 def main():
     fetch_dir, write_dir, steps, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
     fetch, write = counter_sums(fetch_dir, "FETCH_SIZE"), counter_sums(write_dir, "WRITE_SIZE")
-    fam = lambda d: [v for k, v in d.items() if "igemm_kernel" in k or "sgemm_kernel" in k]
+    fam = lambda d: [v for k, v in d.items() if "igemm_kernel" in k or "sgemm_kernel" in k or "hconv_kernel" in k]
     n = sum(v[0] for v in fam(fetch))
     fb = sum(v[1] for v in fam(fetch)) * 2 * 1024
     wb = sum(v[1] for v in fam(write)) * 1024
@@ -49,7 +50,8 @@ def main():
             row["tb_per_s"] = round(b / times[k] / 1e3, 2)
         per_kernel.append((b, row))
     per_kernel.sort(key=lambda t: -t[0])
-    res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on bench.py; GEMM family = igemm_kernel + sgemm_kernel dispatches",
+    res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on bench.py; GEMM family = igemm_kernel + sgemm_kernel + hconv_kernel dispatches",
+           "profiled_commit": os.environ.get("BDETR_COMMIT"), "steps": steps,
            "correction": "FETCH_SIZE x2 (gfx950: 128-B requests tallied at 64 B), units KB -> x1024 (MI355X_MICROARCH.md, HBM section)",
            "steps_in_trace": steps, "igemm_launches": n,
            "fetch_bytes_per_launch": fb / n, "write_bytes_per_launch": wb / n, "hbm_bytes_per_launch": (fb + wb) / n,

@@ -34,7 +34,9 @@ def reduce_dirs(dirs):
                 per[r["Counter_Name"]].append(float(r["Counter_Value"]))
                 if r["Dispatch_Id"] not in seen:
                     seen.add(r["Dispatch_Id"])
-                    names[r["Kernel_Name"].split("(")[0][-90:]] += 1
+                    import re
+                    nm = re.sub(r"\(anonymous namespace\)::|^void |bdgemm::", "", r["Kernel_Name"])
+                    names[re.sub(r"\(.*", "", nm)[:110]] += 1
                     dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     out = {"kernels": dict(names), "dispatches_per_pass": None, "counters": {}}
     for k, v in per.items():
@@ -59,7 +61,7 @@ def main():
         res[label] = reduce_dirs(dirs.split(","))
         print(label, res[label]["derived"], res[label].get("avg_dispatch_us_under_profiler"))
     meta = {"source": "rocprofv3 --pmc <counters> --kernel-trace (counters only; separate passes per counter group), tools/p16_pmc_probe.py",
-            "commit": os.popen("git rev-parse --short HEAD 2>/dev/null").read().strip() or None}
+            "commit": os.environ.get("BDETR_COMMIT") or os.popen("git rev-parse --short HEAD 2>/dev/null").read().strip() or None}
     json.dump({"meta": meta, "probes": res}, open(out_path, "w"), indent=1)
 
 
