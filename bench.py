@@ -145,7 +145,7 @@ def env_overrides() -> dict:
     if bad:
         raise SystemExit(f"bench.py refuses to run with diagnostic switches set ({', '.join(bad)}): they compile work out of the kernels")
     known = set(ENV_REFUSED) | set(ENV_RECORDED)
-    stray = sorted(k for k in os.environ if k.startswith("BDETR_") and k not in known and k != "BDETR_PROF_DUMP")
+    stray = sorted(k for k in os.environ if k.startswith("BDETR_") and k not in known and k not in ("BDETR_PROF_DUMP", "BDETR_COMMIT"))
     return {k: os.environ[k] for k in list(ENV_RECORDED) + stray if k in os.environ}
 
 
