@@ -92,6 +92,7 @@ SIGNATURES = {
     "bdetr_p16_conv2d_bwd_data_bnstats": (I, [P, P, P, C.POINTER(ConvDesc), C.POINTER(BnBwdFuse), P]),
     "bdetr_p16_conv2d_bwd_weight_splitk": (I, [C.POINTER(ConvDesc)]),
     "bdetr_p16_conv2d_bwd_weight": (I, [P, P, P, C.POINTER(ConvDesc), I, P]),
+    "bdetr_p16_conv2d_bwd_weight_xf16": (I, [P, P, P, C.POINTER(ConvDesc), I, P]),
     "bdetr_gemm": (I, [C.POINTER(GemmDesc), P]),
     "bdetr_gemm_grouped": (I, [C.POINTER(GemmDesc), I, P]),
     "bdetr_colsum_chunks": (I, [L]),

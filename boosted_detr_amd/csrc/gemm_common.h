@@ -39,6 +39,9 @@ struct GemmParams {
     // ReLU mask of the element (norm.hip relu_mask_bits4 layout) - the skip branch of a residual unit merged without ever
     // materialising its masked gradient
     const unsigned long long* acc_mask;
+    // (sgemm's XX weight-gradient kernels) the B operand is stored as f16 pairs - the forward operand of the same convolution - and
+    // is converted to bf16 pairs in registers after the fragment read, so that its producer need not write a bf16 copy at all
+    int b_f16;
 #ifdef BDETR_SGEMM_DIAG
     int dbg;                            // diagnostic builds only (tools/epi_probe.py): BDETR_SGEMM_DBG bits 1 = no C stores, 2 = no K loop, 4 = per-element stores, 8 = no fragment reads / MFMAs, 16 = no staging loads
 #endif

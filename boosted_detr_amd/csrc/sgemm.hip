@@ -515,6 +515,19 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
                 }
             }
     };
+    // f16 pair -> bf16 pair of a fragment, element by element (the two 16-bit halves of a dword stay where they are): x = hi + lo is
+    // exact in fp32 (22 bits), then the bf16 split of p16.h.  8 elements: 8 conversions up, 4 adds, 2 x (cvt_pk, 2 expands, 2 subs).
+    auto f16pair_to_bf16pair = [&](u32x4& hi, u32x4& lo) {
+        const unsigned hw[4] = {hi[0], hi[1], hi[2], hi[3]}, lw[4] = {lo[0], lo[1], lo[2], lo[3]};      // (scalars first: see p16_load8)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const p16_f32x2 hf = __builtin_convertvector(__builtin_bit_cast(p16_f16x2, hw[w]), p16_f32x2);
+            const p16_f32x2 lf = __builtin_convertvector(__builtin_bit_cast(p16_f16x2, lw[w]), p16_f32x2);
+            unsigned bh_, bl_;
+            p16_split2_bf16(hf[0] + lf[0], hf[1] + lf[1], bh_, bl_);
+            hi[w] = bh_; lo[w] = bl_;
+        }
+    };
     // One K-step of the plain loops: fragment reads of one 16-deep half, its MFMAs, then the other half
     auto kstep = [&](int buf) {
         if (BDETR_DBG(g, 8)) return;                     // diagnostic builds: no fragment reads / MFMAs
@@ -522,6 +535,12 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
         for (int ks = 0; ks < BK / 16; ++ks) {
             u32x4 ah[TM], al[TM], bh[TN], bl[TN];
             load_frags(buf, ks, ah, al, bh, bl);
+            if constexpr (XX && !F16) {
+                if (g.b_f16) {                           // weight gradients reading the forward's f16 pair of x (see GemmParams::b_f16)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) f16pair_to_bf16pair(bh[b], bl[b]);
+                }
+            }
             mfma_ks(ah, al, bh, bl);
         }
     };
@@ -1022,14 +1041,14 @@ extern "C" int bdetr_p16_conv2d_bwd_weight_splitk(const bdetr_conv_desc* d) {
 
 // x_bf16: P16-bf16 [N,H,W,C]; dy_bf16: P16-bf16 [N,OH,OW,K]; dw: fp32 [K][R][S][C], must hold zeros (or the
 // running sum) when splitk > 1 - the split-K slices add with float atomics
-extern "C" int bdetr_p16_conv2d_bwd_weight(const void* x_bf16, const void* dy_bf16, float* dw,
-                                           const bdetr_conv_desc* d, int splitk, void* stream) {
+static int p16_bwd_weight(const void* x_bf16, int x_is_f16, const void* dy_bf16, float* dw, const bdetr_conv_desc* d, int splitk, void* stream) {
     if (int e = check_conv(d, "bdetr_p16_conv2d_bwd_weight")) return e;
     BDETR_CHECK_ARG(x_bf16 && dy_bf16 && dw, "bdetr_p16_conv2d_bwd_weight: null pointer");
     hipStream_t st = (hipStream_t)stream;
     const int M = d->N * d->OH * d->OW, Kd = d->R * d->S * d->C;
     if (splitk <= 0) splitk = bdetr_p16_conv2d_bwd_weight_splitk(d);
     GemmParams g; init_params(g);
+    g.b_f16 = x_is_f16;
     g.I = d->K; g.J = Kd; g.R = M;
     g.c = dw; g.ldc = Kd;
     int zdim = 1;
@@ -1047,4 +1066,13 @@ extern "C" int bdetr_p16_conv2d_bwd_weight(const void* x_bf16, const void* dy_bf
     }
     PPatch b = make_patch(x_bf16, d->N, d->H, d->W, d->C, d->OH, d->OW, d->R, d->S, d->stride, d->pad, M, Kd);
     return launch_any<XXDense, XXPatch, true, false>(a, b, g, zdim, st, 3000, tile);
+}
+extern "C" int bdetr_p16_conv2d_bwd_weight(const void* x_bf16, const void* dy_bf16, float* dw,
+                                           const bdetr_conv_desc* d, int splitk, void* stream) {
+    return p16_bwd_weight(x_bf16, 0, dy_bf16, dw, d, splitk, stream);
+}
+// x as the FORWARD operand of the same convolution (P16-f16): converted to bf16 pairs in registers, fragment by fragment
+extern "C" int bdetr_p16_conv2d_bwd_weight_xf16(const void* x_f16, const void* dy_bf16, float* dw,
+                                                const bdetr_conv_desc* d, int splitk, void* stream) {
+    return p16_bwd_weight(x_f16, 1, dy_bf16, dw, d, splitk, stream);
 }

@@ -425,7 +425,8 @@ def p16_conv2d_bwd_data_bnstats(dy_bf16, wt_bf16, g: ConvGeom, y_prev, mean, rst
     return dx, (pg, pgx, n)
 
 
-def p16_conv2d_bwd_weight(x_bf16, dy_bf16, g: ConvGeom, dw: Optional[torch.Tensor] = None, prezeroed: bool = False):
+def p16_conv2d_bwd_weight(x_bf16, dy_bf16, g: ConvGeom, dw: Optional[torch.Tensor] = None, prezeroed: bool = False, x_f16: bool = False):
+    """x_f16: `x_bf16` is the P16-f16 tensor the forward read (converted to bf16 pairs inside the kernel)."""
     _chk(x_bf16, dy_bf16, dw)
     L = _lib.lib()
     d = g.desc()
@@ -435,7 +436,8 @@ def p16_conv2d_bwd_weight(x_bf16, dy_bf16, g: ConvGeom, dw: Optional[torch.Tenso
     sk = L.bdetr_p16_conv2d_bwd_weight_splitk(C.byref(d))
     if sk > 1 and not prezeroed:
         check(L.bdetr_zero(_p(dw), dw.numel(), _stream()), "zero")
-    check(L.bdetr_p16_conv2d_bwd_weight(_p(x_bf16), _p(dy_bf16), _p(dw), C.byref(d), sk, _stream()), "p16_conv2d_bwd_weight")
+    fn = L.bdetr_p16_conv2d_bwd_weight_xf16 if x_f16 else L.bdetr_p16_conv2d_bwd_weight
+    check(fn(_p(x_bf16), _p(dy_bf16), _p(dw), C.byref(d), sk, _stream()), "p16_conv2d_bwd_weight")
     return dw
 
 

@@ -158,6 +158,9 @@ def _bn_backward(g2d, out2d, x2d, mean, rstd, bn: BNState, relu: bool, frozen: b
 #   t._p16f / t._p16b   P16-f16 / P16-bf16 copies (fp32-shaped torch tensors, never read as floats)
 #   t._p16_only         the handle IS the f16 copy: no fp32 tensor was materialised (links inside a bottleneck)
 P16_ENABLED = [os.environ.get("BDETR_P16", "1") != "0"]
+# Round 3: the weight gradient reads the f16 pair the FORWARD of its convolution read (converted to bf16 pairs inside the kernel,
+# bdetr_p16_conv2d_bwd_weight_xf16), so activations have no bf16 pair copy at all: bn_apply_p16 writes 4 bytes per element less.
+WGRAD_XF16 = os.environ.get("BDETR_WGRAD_XF16", "1") != "0"
 LAZY_SKIP = os.environ.get("BDETR_LAZY_SKIP", "1") != "0"      # residual units hand their skip gradient on unmasked (conv_bn.backward)
 
 
@@ -179,6 +182,7 @@ def as_fp32(t: torch.Tensor) -> torch.Tensor:
 def _packed_input(x: torch.Tensor, need_bf16: bool):
     """(f16 pair, bf16 pair | None) of an activation, packing an fp32 handle once and caching the result on it."""
     xf, xb = getattr(x, "_p16f", None), getattr(x, "_p16b", None)
+    need_bf16 = need_bf16 and not WGRAD_XF16
     if xf is None or (need_bf16 and xb is None):
         f, b = K.p16_pack(x, want_f16=xf is None, want_bf16=need_bf16 and xb is None)
         xf, xb = (f if xf is None else xf), (b if b is not None else xb)
@@ -266,13 +270,13 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
             out._deferred_bn = (mean, rstd, bn.gamma.value, bn.beta.value)
         else:
             o32, of, ob, *rest = K.bn_apply_p16(y2d, mean, rstd, bn.gamma.value, bn.beta.value, res2d, relu, want_fp32=fp32_out,
-                                                want_f16=want_p16, want_bf16=want_p16, residual_p16=res_p16, want_mask=want_mask,
+                                                want_f16=want_p16, want_bf16=want_p16 and not WGRAD_XF16, residual_p16=res_p16, want_mask=want_mask,
                                                 residual_bn=res_bn)
             relu_bits = rest[0] if want_mask else None
             out2d = o32
             out = (o32 if fp32_out else of).view(N, g.OH, g.OW, Kout)
         if want_p16:
-            out._p16f, out._p16b, out._p16_only = of.view(out.shape), ob.view(out.shape), not fp32_out
+            out._p16f, out._p16b, out._p16_only = of.view(out.shape), (ob.view(out.shape) if ob is not None else None), not fp32_out
         if relu_bits is not None and sole_consumer_is_identity_unit and os.environ.get("BDETR_BN_FUSE", "1") != "0":
             out._bn_ctx_bits = (y2d, mean, rstd, bn.gamma.value, bn.beta.value, relu_bits)
         if not fp32_out and residual is None and os.environ.get("BDETR_BN_FUSE", "1") != "0":
@@ -301,6 +305,7 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
             mask_src, mode = None, 0
             if relu and want_res:
                 mask_src, mode = (out2d, 0) if out2d is not None else ((relu_bits, 2) if relu_bits is not None else (ob, 1))
+                assert mask_src is not None, "a residual unit without an fp32 output keeps its ReLU bit mask"
             pre = getattr(g_out, "_bnb_parts", None)        # the reduction came with the gradient (fused into the consumer's epilogue)
             # The skip gradient of a residual unit is g_out * mask.  With the bit mask at hand it is not written out: the
             # incoming gradient tensor itself is handed to the shortcut's producer tagged with the mask, and the consumers
@@ -321,17 +326,19 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
             sb.commit()
             dyb4 = dyb.view(N, g.OH, g.OW, Kout)
             if w.needs_grad or b.needs_grad:
-                def param_grads(xb=xb, dyb4=dyb4):
+                xw = xf if WGRAD_XF16 else xb           # the weight gradient's x operand: the forward's f16 pair, or a bf16 pair copy
+
+                def param_grads(xw=xw, dyb4=dyb4):
                     if w.needs_grad:
                         s = GradSink(w)
-                        K.p16_conv2d_bwd_weight(xb, dyb4, g, dw=s.buf, prezeroed=s.mode == "direct")
+                        K.p16_conv2d_bwd_weight(xw, dyb4, g, dw=s.buf, prezeroed=s.mode == "direct", x_f16=WGRAD_XF16)
                         s.commit()
                     if b.needs_grad:
                         s = GradSink(b)             # a bias in front of a batch-statistics BN has an exactly zero gradient (see below)
                         if s.mode != "direct":
                             K.zero_(s.buf)
                         s.commit()
-                side_task(param_grads, xb, dyb)
+                side_task(param_grads, xw, dyb)
             dx = None
             if x_needs_grad:
                 _, wt = packed_weights(w, need_bwd=True)

@@ -217,6 +217,11 @@ int bdetr_p16_conv2d_bwd_data_bnstats(const void* dy_bf16, const void* wt_bf16, 
 int bdetr_p16_conv2d_bwd_weight_splitk(const bdetr_conv_desc* d);
 int bdetr_p16_conv2d_bwd_weight(const void* x_bf16, const void* dy_bf16, float* dw,
                                 const bdetr_conv_desc* d, int splitk, void* stream);
+/* The same with x given as the P16-f16 tensor the FORWARD of this convolution read: the kernel converts each fragment to a bf16 pair
+ * in registers ((hi + lo) is exact in fp32, then the bf16 split), so a producer (bdetr_bn_apply_p16, bdetr_p16_pack) need not
+ * write a bf16 copy of an activation at all: 4 bytes per element of HBM traffic and of saved-activation memory less. */
+int bdetr_p16_conv2d_bwd_weight_xf16(const void* x_f16, const void* dy_bf16, float* dw,
+                                     const bdetr_conv_desc* d, int splitk, void* stream);
 
 /* strided-batched GEMM - tf Dense / tf.linalg.matmul call sites
  * (transformers.py:41-48,62-65,86,97,101,174-177; prediction_heads.py:40-43,106-110,175-179)

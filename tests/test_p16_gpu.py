@@ -114,6 +114,8 @@ def p16_conv_case(N, H, W, C, K, R, stride, pad, accumulate=True):
         k.p16_conv2d_bwd_data(dyb, wt, g, dx=dx2, accumulate=True)
         close(dx2, base.double() + xt.grad.permute(0, 2, 3, 1), rtol=6e-5)
     close(k.p16_conv2d_bwd_weight(xb, dyb, g), wtt.grad.permute(0, 2, 3, 1), rtol=6e-5)
+    # the same from the FORWARD's f16 pair of x (converted to bf16 pairs inside the kernel): what the training step uses
+    close(k.p16_conv2d_bwd_weight(xf, dyb, g, x_f16=True), wtt.grad.permute(0, 2, 3, 1), rtol=6e-5)
 
 
 @pytest.mark.parametrize("N,H,W,C,K,R,stride,pad", P16_CONVS + P16_BIG_CONVS)
