@@ -574,9 +574,9 @@ void prof_begin(hipStream_t st, double flops, int I, int J, int R, int z, int bm
     }
     auto& ev = g_prof_pool[g_prof_used++];
     g_prof_recs.push_back({ev.first, ev.second, flops, I, J, R, z, bm, bn, kind});
-    hipEventRecord(ev.first, st);
+    (void)hipEventRecord(ev.first, st);
 }
-void prof_end(hipStream_t st) { hipEventRecord(g_prof_recs.back().e1, st); }
+void prof_end(hipStream_t st) { (void)hipEventRecord(g_prof_recs.back().e1, st); }
 }  // namespace bdgemm
 namespace {
 

@@ -345,8 +345,12 @@ class SegmentedCapture:
         K.set_launch_stream(self.cap_main.cuda_stream)
 
     def end_main(self) -> None:
+        import warnings
         g, ctx = self._cur
-        ctx.__exit__(None, None, None)
+        with warnings.catch_warnings():
+            # a segment may be empty (the cut that closes the backward pass can directly follow a cut by count); an empty graph replays as a no-op
+            warnings.filterwarnings("ignore", message="The CUDA Graph is empty")
+            ctx.__exit__(None, None, None)
         self.mains.append(g)
         self._cur = None
 
