@@ -71,6 +71,9 @@ SIGNATURES = {
     "bdetr_tokens_prepare": (I, [P, P, L, I, I, I, P, P, P]),
     "bdetr_augment_ws_floats": (I, [I]),
     "bdetr_augment": (I, [P, P, P, P, I, I, I, P, P]),
+    "bdetr_jpeg_quality_ws_bytes": (C.c_int64, [I, I, I]),
+    "bdetr_jpeg_quality": (I, [P, P, P, I, I, I, P, P]),
+    "bdetr_augment_jpeg": (I, [P, P, P, P, P, I, I, I, P, P, P]),
     "bdetr_conv2d_fwd": (I, [P, P, P, P, C.POINTER(ConvDesc), I, P, P, P]),
     "bdetr_conv2d_fwd_stat_chunks": (I, [C.POINTER(ConvDesc)]),
     "bdetr_conv2d_bwd_data": (I, [P, P, P, C.POINTER(ConvDesc), I, P]),

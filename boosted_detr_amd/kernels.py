@@ -127,8 +127,9 @@ def tokens_prepare(cat_ids: torch.Tensor, att_ids: torch.Tensor, C_: int, A: int
     return cat, hot
 
 
-def augment(image: torch.Tensor, iparams: torch.Tensor, fparams: torch.Tensor) -> torch.Tensor:
-    """pipeline.py:274-341 on the GPU.  image [B,H,W,3]; iparams int32 [B,4]; fparams f32 [B,3]."""
+def augment(image: torch.Tensor, iparams: torch.Tensor, fparams: torch.Tensor, quality: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """pipeline.py:274-341 on the GPU.  image [B,H,W,3]; iparams int32 [B,4]; fparams f32 [B,3]; quality int32 [B] or None
+    (random_jpeg_quality between brightness and saturation, pipeline.py:319-325)."""
     _chk(image, fparams)
     _chk(iparams, dtype=torch.int32)
     B, H, W, c = image.shape
@@ -136,7 +137,25 @@ def augment(image: torch.Tensor, iparams: torch.Tensor, fparams: torch.Tensor) -
     L = _lib.lib()
     out = torch.empty_like(image)
     ws = empty(L.bdetr_augment_ws_floats(B), like=image)
-    check(L.bdetr_augment(_p(image), _p(out), _p(iparams), _p(fparams), B, H, W, _p(ws), _stream()), "augment")
+    if quality is None:
+        check(L.bdetr_augment(_p(image), _p(out), _p(iparams), _p(fparams), B, H, W, _p(ws), _stream()), "augment")
+        return out
+    _chk(quality, dtype=torch.int32)
+    jws = torch.empty(int(L.bdetr_jpeg_quality_ws_bytes(B, H, W)), dtype=torch.uint8, device=image.device)
+    check(L.bdetr_augment_jpeg(_p(image), _p(out), _p(iparams), _p(fparams), _p(quality), B, H, W, _p(ws), _p(jws), _stream()), "augment_jpeg")
+    return out
+
+
+def jpeg_quality(image: torch.Tensor, quality: torch.Tensor) -> torch.Tensor:
+    """tf.image.adjust_jpeg_quality per image: float [B,H,W,3] in [0,1], quality int32 [B] (device)."""
+    _chk(image)
+    _chk(quality, dtype=torch.int32)
+    B, H, W, c = image.shape
+    assert c == 3 and quality.numel() == B
+    L = _lib.lib()
+    out = torch.empty_like(image)
+    jws = torch.empty(int(L.bdetr_jpeg_quality_ws_bytes(B, H, W)), dtype=torch.uint8, device=image.device)
+    check(L.bdetr_jpeg_quality(_p(image), _p(out), _p(quality), B, H, W, _p(jws), _stream()), "jpeg_quality")
     return out
 
 

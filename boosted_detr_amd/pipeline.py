@@ -62,13 +62,15 @@ def pad_annotations(records: Sequence[dict], max_objects: Optional[int] = None) 
 class Augmentations:
     """pipeline.py:260-341 on the GPU.  ``apply_image_augmentations`` maps over an iterable of batch dicts
     exactly like the reference maps over a tf.data.Dataset (downsizer -> contrast -> brightness ->
-    [jpeg quality: not built] -> saturation); the per-image random draws come from a seeded NumPy
-    generator (TF's stream is not reproducible) and can be injected for tests."""
+    jpeg quality -> saturation); the per-image random draws come from a seeded NumPy generator (TF's
+    stream is not reproducible) and can be injected for tests.  jpeg_quality=False leaves the JPEG
+    round trip out (pipeline.py:319-325: quality uniform in [70, 100))."""
 
     image_key, bbox_key = "image", "bbox"
 
-    def __init__(self, seed: int = 0):
+    def __init__(self, seed: int = 0, jpeg_quality: bool = True):
         self.rng = np.random.Generator(np.random.PCG64(seed))
+        self.jpeg_quality = jpeg_quality
 
     def draw(self, B: int, H: int, W: int) -> Dict[str, np.ndarray]:
         # rand_val = max(1, truncated_normal(mean .5, std .7)): mostly 1 (no down-size), up to ~1.9
@@ -85,7 +87,8 @@ class Augmentations:
         return {"rand_val": rand_val, "new_h": new_h, "new_w": new_w, "off_h": off_h, "off_w": off_w,
                 "contrast": self.rng.uniform(0.8, 1.2, B).astype(np.float32),
                 "brightness": self.rng.uniform(-0.1, 0.1, B).astype(np.float32),
-                "saturation": self.rng.uniform(0.8, 1.2, B).astype(np.float32)}
+                "saturation": self.rng.uniform(0.8, 1.2, B).astype(np.float32),
+                "jpeg_quality": self.rng.integers(70, 100, B).astype(np.int32)}
 
     @staticmethod
     def adjust_boxes(bbox: np.ndarray, p: Dict[str, np.ndarray], H: int, W: int) -> np.ndarray:
@@ -107,7 +110,8 @@ class Augmentations:
         ip = to_device(np.stack([p["new_h"], p["new_w"], p["off_h"], p["off_w"]], axis=-1).astype(np.int32), torch.int32)
         fp = to_device(np.stack([p["contrast"], p["brightness"], p["saturation"]], axis=-1).astype(np.float32))
         out = dict(batch)
-        out[self.image_key] = K.augment(image, ip, fp)
+        q = to_device(np.asarray(p["jpeg_quality"], np.int32), torch.int32) if (self.jpeg_quality and "jpeg_quality" in p) else None
+        out[self.image_key] = K.augment(image, ip, fp, q)
         if self.bbox_key in batch:
             out[self.bbox_key] = self.adjust_boxes(np.asarray(batch[self.bbox_key], np.float32), p, H, W)
         return out

@@ -98,6 +98,18 @@ int bdetr_tokens_prepare(const int* cat_ids, const int* att_ids, int64_t rows, i
 int bdetr_augment_ws_floats(int B);
 int bdetr_augment(const float* in, float* out, const int32_t* iparams, const float* fparams,
                   int B, int H, int W, float* ws, void* stream);
+/* tf.image.random_jpeg_quality / adjust_jpeg_quality (pipeline.py:319-325): per image, float [0,1] -> uint8 (x * 255.5 truncated,
+ * saturating) -> baseline JPEG of quality[b] with 4:2:0 chroma -> decode -> / 255.  Only the lossy stages of the codec run (colour
+ * conversion, chroma down-sampling, 8x8 integer DCT, quantisation with the quality-scaled Annex K tables, inverse DCT, fancy
+ * up-sampling); entropy coding is lossless and skipped.  The codec is a third-party dependency of the reference (libjpeg-turbo inside
+ * TensorFlow): bit-exact against a real libjpeg-turbo through oracle/jpeg_oracle.py (tests/test_jpeg_quality.py).  in == out allowed.
+ * quality: int32 [B] on the device; ws: bdetr_jpeg_quality_ws_bytes(B, H, W) bytes. */
+int64_t bdetr_jpeg_quality_ws_bytes(int B, int H, int W);
+int bdetr_jpeg_quality(const float* in, float* out, const int32_t* quality, int B, int H, int W, void* ws, void* stream);
+/* bdetr_augment with the JPEG round trip between brightness and saturation, where the reference has it (pipeline.py:364-383);
+ * quality == NULL: exactly bdetr_augment */
+int bdetr_augment_jpeg(const float* in, float* out, const int32_t* iparams, const float* fparams, const int32_t* quality,
+                       int B, int H, int W, float* ws, void* jpeg_ws, void* stream);
 
 /* ------------------------------------------------------------------------
  * K2/K5/K6  MFMA implicit-GEMM family (v_mfma_f32_32x32x2_f32, LDS-staged tiles).

@@ -7,7 +7,7 @@ Restates /root/reference/ModelComponents/pipeline.py:274-341 with the tf.image s
   * tf.image.adjust_contrast: (x - mean_c) * f + mean_c, mean over H,W per channel
   * tf.image.adjust_brightness: x + delta
   * tf.image.adjust_saturation: adjust_saturation_op.cc's rgb->hsv, s = clamp(s*f,0,1), hsv->rgb
-  * random_jpeg_quality (319-325) is not restated (needs a JPEG codec).
+  * tf.image.random_jpeg_quality (319-325): oracle/jpeg_oracle.py (that part IS pinned: bit-exact against libjpeg-turbo)
 The random draws are inputs (TF's RNG is not reproducible)."""
 import numpy as np
 import torch
@@ -53,11 +53,14 @@ def adjust_saturation(img: np.ndarray, scale: float) -> np.ndarray:
 
 
 def augment(image: np.ndarray, p: dict, b: int) -> np.ndarray:
-    """One image [H,W,3] through downsizer -> contrast -> brightness -> saturation (fp64)."""
+    """One image [H,W,3] through downsizer -> contrast -> brightness -> [jpeg quality] -> saturation (fp64)."""
     x = downsize_with_pad(image, int(p["new_h"][b]), int(p["new_w"][b]), int(p["off_h"][b]), int(p["off_w"][b]))
     mean = x.mean(axis=(0, 1), keepdims=True)
     x = (x - mean) * float(p["contrast"][b]) + mean
     x = x + float(p["brightness"][b])
+    if "jpeg_quality" in p:
+        from . import jpeg_oracle
+        x = jpeg_oracle.adjust_jpeg_quality(x, int(p["jpeg_quality"][b])).astype(np.float64)
     return adjust_saturation(x, float(p["saturation"][b]))
 
 

@@ -38,8 +38,9 @@ def test_gpu_augment_matches_oracle(cuda):
     rng = np.random.default_rng(1)
     B, H, W = 4, 48, 80
     image = rng.random((B, H, W, 3), dtype=np.float32)
-    aug = Augmentations(seed=5)
+    aug = Augmentations(seed=5, jpeg_quality=False)
     p = aug.draw(B, H, W)
+    quality = p.pop("jpeg_quality")                                 # first without the JPEG round trip: fp32 against fp64 to 2e-5
     p["rand_val"][0] = [1.0, 1.0]; p["new_h"][0], p["new_w"][0], p["off_h"][0], p["off_w"][0] = H, W, 0, 0     # identity geometry
     p["rand_val"][1] = [1.7, 1.3]; p["new_h"][1], p["new_w"][1] = int(np.float32(H) / np.float32(1.7)), int(np.float32(W) / np.float32(1.3))
     p["off_h"][1], p["off_w"][1] = 5, 11
@@ -51,6 +52,14 @@ def test_gpu_augment_matches_oracle(cuda):
         err = np.abs(got[b] - want).max()
         assert err < 2e-5, (b, err)
     assert np.allclose(out["bbox"], AO.adjust_boxes(batch["bbox"], p, H, W), atol=1e-6)
+    # with the JPEG round trip (between brightness and saturation, pipeline.py:364-383): a last-bit difference of the fp32 chain in front
+    # of it can move a pixel across a uint8 boundary, and the lossy codec spreads that over its 8x8 block - so this is statistical; the
+    # codec itself is compared bit for bit in tests/test_jpeg_quality.py
+    p["jpeg_quality"] = quality
+    got = Augmentations(seed=5).apply(batch, params=p)["image"].cpu().numpy().astype(np.float64)
+    for b in range(B):
+        d = np.abs(got[b] - AO.augment(image[b], p, b))
+        assert d.mean() < 0.5 / 255 and (d <= 4.0 / 255).mean() > 0.99, (b, d.mean(), d.max())
     # the generator form maps a stream of batches
     outs = list(Augmentations(seed=1).apply_image_augmentations([batch, batch]))
     assert len(outs) == 2 and tuple(outs[0]["image"].shape) == (B, H, W, 3)
