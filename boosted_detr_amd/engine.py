@@ -354,6 +354,19 @@ class SegmentedCapture:
         self.mains.append(g)
         self._cur = None
 
+    def abort(self) -> None:
+        """A step failed while a main segment was being captured: end that capture (its graph is dropped) so that the stream leaves
+        capture mode; the exception that caused it propagates from the caller."""
+        if self._cur is not None:
+            import sys
+            _, ctx = self._cur
+            self._cur = None
+            try:
+                ctx.__exit__(*sys.exc_info())
+            except Exception:
+                pass
+        self.pending, self.done = [], []
+
     def capture_side(self) -> None:
         if not self.pending:
             self.sides.append(None)

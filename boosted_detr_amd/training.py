@@ -640,6 +640,10 @@ class Model(Layer):
                 logs = self._device_step(static, stage_scalars=False)
                 cap.end_main()
                 cap.sides.append(None)                       # (the optimizer segment has no side work)
+            except BaseException:
+                cap.abort()                                  # close the open capture: the stream must not stay in capture mode
+                self.steps_done, self.optimizer.iterations = keep
+                raise
             finally:
                 _engine._CAPTURE[0] = None
                 K.set_launch_stream(prev_launch)

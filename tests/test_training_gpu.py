@@ -462,3 +462,32 @@ def test_non_finite_gradient_raises_the_guard_and_applies_nothing(cuda):
     opt.apply_gradients(skip_flag=flag)                # a clean gradient goes through
     torch.cuda.synchronize()
     assert int(flag.item()) == 0 and any(not torch.equal(a, v.value) for a, v in zip(before, tv))
+
+
+def test_a_step_that_fails_during_capture_leaves_the_stream_usable(cuda):
+    """An exception inside the captured step must end the open capture (engine.SegmentedCapture.abort): the next step - eager or a fresh
+    capture - runs, counters are where they were."""
+    from boosted_detr_amd.engine import to_device
+    from boosted_detr_amd.training import SGD
+    cfg, host = small_batch()
+    batch = {"image": to_device(host["image"]), "category": to_device(host["category"], torch.int32),
+             "attribute": to_device(host["attribute"], torch.int32), "bbox": to_device(host["bbox"]),
+             "num_objects": to_device(host["num_objects"], torch.int32)}
+    m = small_model()
+    opt = SGD(learning_rate=1e-3, momentum=.9, nesterov=True, clipnorm=.1)
+    m.compile(optimizer=opt)
+    m.use_graph = True
+    m.train_step(batch); m.train_step(batch)                       # two eager steps; the third captures
+    real = opt.apply_gradients
+
+    def boom(*a, **k):
+        raise RuntimeError("boom")
+    opt.apply_gradients = boom
+    steps = (m.steps_done, opt.iterations)
+    with pytest.raises(RuntimeError, match="boom"):
+        m.train_step(batch)
+    opt.apply_gradients = real
+    assert (m.steps_done, opt.iterations) == steps and not m._graphs
+    assert not torch.cuda.is_current_stream_capturing()
+    loss = m.logs_to_host(m.train_step(batch))["loss"]             # captures now (or runs eagerly): either way a valid step
+    assert np.isfinite(loss) and m.steps_done == steps[0] + 1
