@@ -38,13 +38,13 @@ class _ConvBN(Layer):
         self.built = True
 
     def call(self, inputs, training=False, relu=True, residual=None, x_needs_grad=True, want_fp32=True, want_p16=False, defer_apply=False,
-             next_is_identity_unit=False):
+             next_is_identity_unit=False, want_bf16=False):
         x = inputs[0]
         # S18: BN uses batch statistics only when training AND the layer is trainable
         return ops.conv_bn(x, self.kernel, self.bias, self.bn, self.stride, self.pad, relu, residual=residual,
                            training=training, bn_batch_stats=training and self.trainable, x_needs_grad=x_needs_grad,
                            want_fp32=want_fp32, want_p16=want_p16, defer_apply=defer_apply,
-                           sole_consumer_is_identity_unit=next_is_identity_unit)
+                           sole_consumer_is_identity_unit=next_is_identity_unit, want_bf16=want_bf16)
 
 
 class ResNet(Layer):
@@ -87,7 +87,9 @@ class ResNet(Layer):
             last = i + 1 == len(self.blocks)
             # projection shortcut: its BatchNorm is applied inside c3's pass (ops.conv_bn defer_apply)
             sc = blk["short"]([x], training=training, relu=False, defer_apply=True) if blk["short"] is not None else x
-            y = blk["c1"]([x], training=training, relu=True, want_fp32=False, want_p16=True)
+            # (c1's output feeds the 3x3: a quarter-width tensor whose bf16 pair copy is cheap and keeps the MFMA-bound 3x3 weight
+            # gradient free of the in-register f16 -> bf16 conversion the wide 1x1 layers' weight gradients do instead, ops.conv_bn)
+            y = blk["c1"]([x], training=training, relu=True, want_fp32=False, want_p16=True, want_bf16=True)
             y = blk["c2"]([y], training=training, relu=True, want_fp32=False, want_p16=True)
             nxt_identity = not last and self.blocks[i + 1]["short"] is None       # the next unit reads x through its c1 and its identity skip only
             x = blk["c3"]([y], training=training, relu=True, residual=sc, want_fp32=last, want_p16=not last,

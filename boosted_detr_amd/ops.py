@@ -161,6 +161,7 @@ P16_ENABLED = [os.environ.get("BDETR_P16", "1") != "0"]
 # Round 3: the weight gradient reads the f16 pair the FORWARD of its convolution read (converted to bf16 pairs inside the kernel,
 # bdetr_p16_conv2d_bwd_weight_xf16), so activations have no bf16 pair copy at all: bn_apply_p16 writes 4 bytes per element less.
 WGRAD_XF16 = os.environ.get("BDETR_WGRAD_XF16", "1") != "0"
+BF16_FOR_3X3 = os.environ.get("BDETR_BF16_3X3", "1") != "0"       # ... except in front of a 3x3 convolution (conv_bn want_bf16)
 LAZY_SKIP = os.environ.get("BDETR_LAZY_SKIP", "1") != "0"      # residual units hand their skip gradient on unmasked (conv_bn.backward)
 
 
@@ -230,7 +231,7 @@ def packed_weights(w: Variable, need_bwd: bool = True):
 def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int, pad: int, relu: bool,
             residual: Optional[torch.Tensor] = None, training: bool = False, bn_batch_stats: Optional[bool] = None,
             x_needs_grad: bool = True, want_fp32: bool = True, want_p16: bool = False, defer_apply: bool = False,
-            sole_consumer_is_identity_unit: bool = False) -> torch.Tensor:
+            sole_consumer_is_identity_unit: bool = False, want_bf16: bool = False) -> torch.Tensor:
     """Conv2D(+bias) -> BatchNormalization -> [+ residual] -> [ReLU]  (keras ResNet-50 block unit).
 
     sole_consumer_is_identity_unit (residual units): the only consumers of this output are the next unit's first 1x1
@@ -240,7 +241,9 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
     tensor is not written - the returned handle is the RAW convolution output tagged `_deferred_bn`, and the unit that takes
     it as `residual` applies both BatchNorms in its one pass (bn_apply_p16 residual_bn; as_fp32 is the fallback).
 
-    want_p16: the consumer is another conv_bn - also emit the packed copies of the output (P16 path only);
+    want_p16: the consumer is another conv_bn - also emit the packed copy of the output (P16 path only): the f16 pair, which feeds
+    the consumer's forward AND (converted in registers) its weight gradient; want_bf16: additionally a bf16 pair copy for that weight
+    gradient - worth its 4 bytes per element only for the quarter-width tensor in front of a 3x3 convolution;
     want_fp32=False: no fp32 output at all, the returned handle is the f16 copy (valid on the P16 path only,
     otherwise ignored)."""
     N, H, W, Cin = x.shape
@@ -270,7 +273,7 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
             out._deferred_bn = (mean, rstd, bn.gamma.value, bn.beta.value)
         else:
             o32, of, ob, *rest = K.bn_apply_p16(y2d, mean, rstd, bn.gamma.value, bn.beta.value, res2d, relu, want_fp32=fp32_out,
-                                                want_f16=want_p16, want_bf16=want_p16 and not WGRAD_XF16, residual_p16=res_p16, want_mask=want_mask,
+                                                want_f16=want_p16, want_bf16=want_p16 and ((want_bf16 and BF16_FOR_3X3) or not WGRAD_XF16), residual_p16=res_p16, want_mask=want_mask,
                                                 residual_bn=res_bn)
             relu_bits = rest[0] if want_mask else None
             out2d = o32
@@ -326,12 +329,12 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
             sb.commit()
             dyb4 = dyb.view(N, g.OH, g.OW, Kout)
             if w.needs_grad or b.needs_grad:
-                xw = xf if WGRAD_XF16 else xb           # the weight gradient's x operand: the forward's f16 pair, or a bf16 pair copy
+                xw, xw_f16 = (xb, False) if xb is not None else (xf, True)     # the weight gradient's x operand: a bf16 pair copy where the producer wrote one, else the forward's f16 pair
 
-                def param_grads(xw=xw, dyb4=dyb4):
+                def param_grads(xw=xw, xw_f16=xw_f16, dyb4=dyb4):
                     if w.needs_grad:
                         s = GradSink(w)
-                        K.p16_conv2d_bwd_weight(xw, dyb4, g, dw=s.buf, prezeroed=s.mode == "direct", x_f16=WGRAD_XF16)
+                        K.p16_conv2d_bwd_weight(xw, dyb4, g, dw=s.buf, prezeroed=s.mode == "direct", x_f16=xw_f16)
                         s.commit()
                     if b.needs_grad:
                         s = GradSink(b)             # a bias in front of a batch-statistics BN has an exactly zero gradient (see below)
