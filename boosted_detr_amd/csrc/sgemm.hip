@@ -1022,11 +1022,11 @@ static int wgrad_tile(const bdetr_conv_desc* d) {
     const int forced = forced_tile();
     if (forced >= 0 && d->K % TILE_BM[forced] == 0 && Kd % TILE_BN[forced] == 0) return forced;
     if (!(d->K % 128 == 0 && Kd % 128 == 0)) return T_64x64;
-    // 1x1 stride-1 layers: 128x64 (twice the workgroups per split-K slice, half the x-operand fragments per wave) measured 5-10 % faster
-    // than 128x128 on 11 of the 13 layer shapes of ResNet-50 at batch 16 (tools/p16_bench.py, round 3); the stride-2 projections not
+    // 1x1 layers: 128x64 (twice the workgroups per split-K slice, half the x-operand fragments per wave) measured 5-25 % faster than
+    // 128x128 on 13 of the 16 layer shapes of ResNet-50 at batch 16 (tools/tile_sweep.py, round 3); the stride-2 projections (K = 2 C) not
     static int wide = -1;
     if (wide < 0) { const char* e = getenv("BDETR_WGRAD_1X1_TILE"); wide = (e && !strcmp(e, "128x128")) ? 1 : 0; }     // (A/B switch)
-    if (d->R == 1 && d->S == 1 && d->stride == 1 && !wide) return T_128x64;
+    if (d->R == 1 && d->S == 1 && !(d->stride > 1 && d->K > d->C) && !wide) return T_128x64;
     return T_128x128;
 }
 
