@@ -97,6 +97,10 @@ SIGNATURES = {
     "bdetr_p16_conv2d_bwd_weight": (I, [P, P, P, C.POINTER(ConvDesc), I, P]),
     "bdetr_p16_conv2d_bwd_weight_xf16": (I, [P, P, P, C.POINTER(ConvDesc), I, P]),
     "bdetr_gemm": (I, [C.POINTER(GemmDesc), P]),
+    "bdetr_gemm_ws": (I, [C.POINTER(GemmDesc), P, L, P]),
+    "bdetr_splitk_workspace_elems": (L, [L, L, I]),
+    "bdetr_conv2d_bwd_weight_ws": (I, [P, P, P, C.POINTER(ConvDesc), I, P, L, P]),
+    "bdetr_p16_conv2d_bwd_weight_ws": (I, [P, I, P, P, C.POINTER(ConvDesc), I, P, L, P]),
     "bdetr_gemm_grouped": (I, [C.POINTER(GemmDesc), I, P]),
     "bdetr_colsum_chunks": (I, [L]),
     "bdetr_colsum": (I, [P, L, I, P, P, P]),
@@ -172,7 +176,7 @@ def lib():
         fn = getattr(h, name)          # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if h.bdetr_abi_version() != 5:
+    if h.bdetr_abi_version() != 6:
         raise BdetrError("libbdetr.so ABI version mismatch; rebuild")
     _lib = h
     return _lib

@@ -47,14 +47,21 @@ def build(force: bool = False, verbose: bool = True) -> Path:
     OBJ_DIR.mkdir(exist_ok=True)
     hipcc = _hipcc()
 
+    headers = [d for d in deps if d.suffix == ".h"]
+
     def compile_one(src: str) -> Path:
+        # one stamp per object: a change to one translation unit recompiles that unit only (a header change recompiles all)
         obj = OBJ_DIR / (src.rsplit(".", 1)[0] + ".o")
         flags = COMMON_FLAGS + PER_FILE_FLAGS.get(src, [])
-        lang = ["-x", "hip"] if src.endswith(".hip") else ["-x", "hip"]
-        cmd = [hipcc, *flags, *lang, "-c", str(CSRC / src), "-o", str(obj)]
+        ostamp = OBJ_DIR / (src + ".stamp")
+        odig = _digest([CSRC / src] + headers) + "|" + " ".join(flags)
+        if not force and obj.exists() and ostamp.exists() and ostamp.read_text() == odig:
+            return obj
+        cmd = [hipcc, *flags, "-x", "hip", "-c", str(CSRC / src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
+        ostamp.write_text(odig)
         return obj
 
     with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:

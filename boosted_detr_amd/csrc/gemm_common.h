@@ -318,6 +318,11 @@ extern bool g_prof_on;
 void prof_begin(hipStream_t st, double flops, int I, int J, int R, int z, int bm, int bn, int kind);
 void prof_end(hipStream_t st);
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+// Deterministic split-K (the *_ws entry points): slice z of a split-K launch stores its partial C tile at ws + z * slab (mode
+// ST_STORE, GemmParams::sc0 = slab) instead of adding it to C with float atomics; splitk_fold then adds the slabs to C in the
+// fixed order z = 0 .. zdim - 1.  slab = splitk_slab(I * J); ws holds at least splitk * slab floats and is 16-byte aligned.
+inline int64_t splitk_slab(int64_t elems) { return (elems + 3) / 4 * 4; }
+int splitk_fold(const float* ws, int zdim, int64_t slab, float* dst, int64_t n, hipStream_t st);
 
 // ---- hconv.hip: 3x3 / stride 1 / pad 1 convolutions with the input halo resident in LDS ----
 int hconv_tile(int64_t rows, int W, int C, int J, bool f16);          // BM * 1000 + BN, or 0: stay on sgemm.hip's im2col kernel

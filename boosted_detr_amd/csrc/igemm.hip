@@ -469,7 +469,8 @@ void igemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[a][b][e] += acc2[a][b][e] * (1.f / LO_SCALE);
     }
-    gemm_epilogue<BM, BN, WM, WN, NTHREADS, 2 * STAGE_FLOATS>(acc, g, lds, tile_i, i0, j0, g.c + (int64_t)b0 * g.sc0 + (int64_t)b1 * g.sc1);
+    // split-K with ST_STORE (deterministic mode): slice zz_ stores its partial tile in its own slab, sc0 floats apart (fold: splitk_fold)
+    gemm_epilogue<BM, BN, WM, WN, NTHREADS, 2 * STAGE_FLOATS>(acc, g, lds, tile_i, i0, j0, g.c + (int64_t)(sk_ ? zz_ : b0) * g.sc0 + (int64_t)b1 * g.sc1);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -634,7 +635,37 @@ int stat_chunks(int I, int J) {
     return (int)cdiv64(I, t.bm) * wm;
 }
 
+// dst[i] += ws[0][i] + ws[1][i] + ... in that order: the fixed-order fold of the deterministic split-K mode
+__global__ __launch_bounds__(256) void splitk_fold_kernel(const float* __restrict__ ws, int zdim, int64_t slab, float* __restrict__ dst, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    if (i + 4 <= n && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+        f32x4 a = *reinterpret_cast<const f32x4*>(ws + i);
+        for (int z = 1; z < zdim; ++z) a += *reinterpret_cast<const f32x4*>(ws + (int64_t)z * slab + i);
+        f32x4 d = *reinterpret_cast<f32x4*>(dst + i);
+        d += a;
+        *reinterpret_cast<f32x4*>(dst + i) = d;
+    } else {
+        for (int64_t k = i; k < n && k < i + 4; ++k) {
+            float a = ws[k];
+            for (int z = 1; z < zdim; ++z) a += ws[(int64_t)z * slab + k];
+            dst[k] += a;
+        }
+    }
+}
+
 }  // namespace
+
+namespace bdgemm {
+int splitk_fold(const float* ws, int zdim, int64_t slab, float* dst, int64_t n, hipStream_t st) {
+    hipLaunchKernelGGL(splitk_fold_kernel, dim3((unsigned)cdiv64(cdiv64(n, 4), 256)), dim3(256), 0, st, ws, zdim, slab, dst, n);
+    return bdetr_launch_status("splitk_fold");
+}
+}  // namespace bdgemm
+
+extern "C" int64_t bdetr_splitk_workspace_elems(int64_t I, int64_t J, int splitk) {
+    return splitk > 1 ? (int64_t)splitk * bdgemm::splitk_slab(I * J) : 0;
+}
 
 // ----------------------------------------------------------------------------------------
 // C ABI
@@ -729,7 +760,22 @@ extern "C" int bdetr_gemm_grouped(const bdetr_gemm_desc* d, int n, void* stream)
     return launch_any<DenseLoader<4>, false, DenseLoader<4>, true>(a, b, g, n, st, sp, true);
 }
 
-extern "C" int bdetr_gemm(const bdetr_gemm_desc* d, void* stream) {
+extern "C" int bdetr_gemm(const bdetr_gemm_desc* d, void* stream) { return bdetr_gemm_ws(d, nullptr, 0, stream); }
+
+template <class F>
+static int with_splitk_slabs(GemmParams& g, int zdim, float* ws, int64_t ws_elems, hipStream_t st, const char* who, F&& launch) {
+    // deterministic split-K: the slices store into slabs of the caller's workspace, a second launch folds them into C in order
+    float* c = g.c;
+    const int64_t n = (int64_t)g.I * g.J, slab = splitk_slab(n);
+    BDETR_CHECK_ARG(g.ldc == g.J, "%s: the split-K workspace form needs a dense C (ldc == J)", who);
+    BDETR_CHECK_ARG(aligned16(ws) && ws_elems >= (int64_t)zdim * slab, "%s: workspace too small or misaligned (%lld floats, need %lld)", who,
+                    (long long)ws_elems, (long long)((int64_t)zdim * slab));
+    g.c = ws; g.sc0 = slab; g.mode = ST_STORE;
+    if (int e = launch()) return e;
+    return splitk_fold(ws, zdim, slab, c, n, st);
+}
+
+extern "C" int bdetr_gemm_ws(const bdetr_gemm_desc* d, float* ws, int64_t ws_elems, void* stream) {
     BDETR_CHECK_ARG(d && d->a && d->b && d->c, "bdetr_gemm: null pointer");
     BDETR_CHECK_ARG(d->I > 0 && d->J > 0 && d->R >= 0, "bdetr_gemm: bad shape I=%d J=%d R=%d", d->I, d->J, d->R);
     const int nb0 = d->nb0 > 0 ? d->nb0 : 1, nb1 = d->nb1 > 0 ? d->nb1 : 1;
@@ -759,17 +805,21 @@ extern "C" int bdetr_gemm(const bdetr_gemm_desc* d, void* stream) {
     const bool v4 = vec_ok(a) && vec_ok(b);
     const bool arc = d->a_rcontig != 0, brc = d->b_rcontig != 0;
     const int sp = use_split(d->grad != 0);
-    if (v4) {
-        if (arc && brc)   return launch_any<DenseLoader<4>, true, DenseLoader<4>, true>(a, b, g, zdim, st, sp);
-        if (arc && !brc)  return launch_any<DenseLoader<4>, true, DenseLoader<4>, false>(a, b, g, zdim, st, sp);
-        if (!arc && !brc) return launch_any<DenseLoader<4>, false, DenseLoader<4>, false>(a, b, g, zdim, st, sp);
-        return launch_any<DenseLoader<4>, false, DenseLoader<4>, true>(a, b, g, zdim, st, sp, true);
-    }
-    // unaligned fallback (scalar HBM loads): only tiny problems take it (82-wide heads, T=49 attention)
-    if (arc && brc)   return launch_any<DenseLoader<1>, true, DenseLoader<1>, true>(a, b, g, zdim, st, AR_FP32, true);
-    if (arc && !brc)  return launch_any<DenseLoader<1>, true, DenseLoader<1>, false>(a, b, g, zdim, st, AR_FP32, true);
-    if (!arc && !brc) return launch_any<DenseLoader<1>, false, DenseLoader<1>, false>(a, b, g, zdim, st, AR_FP32, true);
-    return launch_any<DenseLoader<1>, false, DenseLoader<1>, true>(a, b, g, zdim, st, AR_FP32, true);
+    auto launch = [&]() -> int {
+        if (v4) {
+            if (arc && brc)   return launch_any<DenseLoader<4>, true, DenseLoader<4>, true>(a, b, g, zdim, st, sp);
+            if (arc && !brc)  return launch_any<DenseLoader<4>, true, DenseLoader<4>, false>(a, b, g, zdim, st, sp);
+            if (!arc && !brc) return launch_any<DenseLoader<4>, false, DenseLoader<4>, false>(a, b, g, zdim, st, sp);
+            return launch_any<DenseLoader<4>, false, DenseLoader<4>, true>(a, b, g, zdim, st, sp, true);
+        }
+        // unaligned fallback (scalar HBM loads): only tiny problems take it (82-wide heads, T=49 attention)
+        if (arc && brc)   return launch_any<DenseLoader<1>, true, DenseLoader<1>, true>(a, b, g, zdim, st, AR_FP32, true);
+        if (arc && !brc)  return launch_any<DenseLoader<1>, true, DenseLoader<1>, false>(a, b, g, zdim, st, AR_FP32, true);
+        if (!arc && !brc) return launch_any<DenseLoader<1>, false, DenseLoader<1>, false>(a, b, g, zdim, st, AR_FP32, true);
+        return launch_any<DenseLoader<1>, false, DenseLoader<1>, true>(a, b, g, zdim, st, AR_FP32, true);
+    };
+    if (ws != nullptr && splitk > 1) return with_splitk_slabs(g, zdim, ws, ws_elems, st, "bdetr_gemm_ws", launch);
+    return launch();
 }
 
 static int check_conv(const bdetr_conv_desc* d, const char* who) {
@@ -861,6 +911,10 @@ extern "C" int bdetr_conv2d_bwd_weight_splitk(const bdetr_conv_desc* d) {
 
 extern "C" int bdetr_conv2d_bwd_weight(const float* x, const float* dy, float* dw,
                                        const bdetr_conv_desc* d, int splitk, void* stream) {
+    return bdetr_conv2d_bwd_weight_ws(x, dy, dw, d, splitk, nullptr, 0, stream);
+}
+extern "C" int bdetr_conv2d_bwd_weight_ws(const float* x, const float* dy, float* dw,
+                                          const bdetr_conv_desc* d, int splitk, float* ws, int64_t ws_elems, void* stream) {
     if (int e = check_conv(d, "bdetr_conv2d_bwd_weight")) return e;
     BDETR_CHECK_ARG(x && dy && dw, "bdetr_conv2d_bwd_weight: null pointer");
     BDETR_CHECK_ARG(d->K % 4 == 0, "bdetr_conv2d_bwd_weight: output channels must be a multiple of 4");
@@ -878,10 +932,14 @@ extern "C" int bdetr_conv2d_bwd_weight(const float* x, const float* dy, float* d
         g.mode = ST_ATOMIC;
     }
     DenseOp a{dy, d->K, 0, 0, M, d->K};           // rows = r (pixels), cols = i (k)
-    if (d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0) {
-        DenseOp b{x, d->C, 0, 0, M, d->C};
-        return launch_any<DenseLoader<4>, false, DenseLoader<4>, false>(a, b, g, zdim, st, use_split(true));
-    }
-    PatchOp b{x, d->N, d->H, d->W, d->C, d->OH, d->OW, d->R, d->S, d->stride, d->pad, M, Kd};
-    return launch_any<DenseLoader<4>, false, PatchLoader, false>(a, b, g, zdim, st, use_split(true));
+    auto launch = [&]() -> int {
+        if (d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0) {
+            DenseOp b{x, d->C, 0, 0, M, d->C};
+            return launch_any<DenseLoader<4>, false, DenseLoader<4>, false>(a, b, g, zdim, st, use_split(true));
+        }
+        PatchOp b{x, d->N, d->H, d->W, d->C, d->OH, d->OW, d->R, d->S, d->stride, d->pad, M, Kd};
+        return launch_any<DenseLoader<4>, false, PatchLoader, false>(a, b, g, zdim, st, use_split(true));
+    };
+    if (ws != nullptr && splitk > 1) return with_splitk_slabs(g, zdim, ws, ws_elems, st, "bdetr_conv2d_bwd_weight_ws", launch);
+    return launch();
 }

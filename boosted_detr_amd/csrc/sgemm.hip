@@ -618,7 +618,7 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
             atomic_epilogue<BM, BN, WM, WN>(acc, g, i0, j0);
             return;
         }
-        gemm_epilogue<BM, BN, WM, WN, NT, LDS_BYTES / 4>(acc, g, reinterpret_cast<float*>(lds), tile_i, i0, j0, g.c, bias_pre);
+        gemm_epilogue<BM, BN, WM, WN, NT, LDS_BYTES / 4>(acc, g, reinterpret_cast<float*>(lds), tile_i, i0, j0, g.c + (g.splitk > 1 ? (int64_t)zz * g.sc0 : 0), bias_pre);
     } else if constexpr (PERSIST) {
         // Two-stage ring, persistent over tiles.  Per K-step: wait for everything this wave has in flight (stage kt, and
         // on a tile's first step the previous tile's C stores - on gfx9 stores count in vmcnt and return out of order with
@@ -706,7 +706,7 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
             atomic_epilogue<BM, BN, WM, WN>(acc, g, i0, j0);
             return;
         }
-        gemm_epilogue<BM, BN, WM, WN, NT, LDS_BYTES / 4, (EPI & EPI_VEC) != 0>(acc, g, reinterpret_cast<float*>(lds), tile_i, i0, j0, g.c, bias_pre);
+        gemm_epilogue<BM, BN, WM, WN, NT, LDS_BYTES / 4, (EPI & EPI_VEC) != 0>(acc, g, reinterpret_cast<float*>(lds), tile_i, i0, j0, g.c + (g.splitk > 1 ? (int64_t)zz * g.sc0 : 0), bias_pre);
     }
 }
 
@@ -1055,7 +1055,8 @@ extern "C" int bdetr_p16_conv2d_bwd_weight_splitk(const bdetr_conv_desc* d) {
 
 // x_bf16: P16-bf16 [N,H,W,C]; dy_bf16: P16-bf16 [N,OH,OW,K]; dw: fp32 [K][R][S][C], must hold zeros (or the
 // running sum) when splitk > 1 - the split-K slices add with float atomics
-static int p16_bwd_weight(const void* x_bf16, int x_is_f16, const void* dy_bf16, float* dw, const bdetr_conv_desc* d, int splitk, void* stream) {
+static int p16_bwd_weight(const void* x_bf16, int x_is_f16, const void* dy_bf16, float* dw, const bdetr_conv_desc* d, int splitk, void* stream,
+                          float* ws = nullptr, int64_t ws_elems = 0) {
     if (int e = check_conv(d, "bdetr_p16_conv2d_bwd_weight")) return e;
     BDETR_CHECK_ARG(x_bf16 && dy_bf16 && dw, "bdetr_p16_conv2d_bwd_weight: null pointer");
     hipStream_t st = (hipStream_t)stream;
@@ -1074,12 +1075,27 @@ static int p16_bwd_weight(const void* x_bf16, int x_is_f16, const void* dy_bf16,
     }
     PDense a{dy_bf16, (unsigned)d->K, M, d->K};          // rows = r (pixels), cols = i (output channels)
     const int tile = wgrad_tile(d);
+    const bool slabs = ws != nullptr && splitk > 1;      // deterministic mode: partial tiles to the caller's workspace, fixed-order fold
+    const int64_t n = (int64_t)d->K * Kd, slab = splitk_slab(n);
+    if (slabs) {
+        BDETR_CHECK_ARG(aligned16(ws) && ws_elems >= (int64_t)zdim * slab, "bdetr_p16_conv2d_bwd_weight_ws: workspace too small or misaligned (%lld floats, need %lld)",
+                        (long long)ws_elems, (long long)((int64_t)zdim * slab));
+        g.c = ws; g.sc0 = slab; g.mode = ST_STORE;
+    }
+    int e;
     if (is_1x1_dense(d)) {
         PDense b{x_bf16, (unsigned)d->C, M, d->C};
-        return launch_any<XXDense, XXDense, true, false>(a, b, g, zdim, st, 2000, tile);
+        e = launch_any<XXDense, XXDense, true, false>(a, b, g, zdim, st, 2000, tile);
+    } else {
+        PPatch b = make_patch(x_bf16, d->N, d->H, d->W, d->C, d->OH, d->OW, d->R, d->S, d->stride, d->pad, M, Kd);
+        e = launch_any<XXDense, XXPatch, true, false>(a, b, g, zdim, st, 3000, tile);
     }
-    PPatch b = make_patch(x_bf16, d->N, d->H, d->W, d->C, d->OH, d->OW, d->R, d->S, d->stride, d->pad, M, Kd);
-    return launch_any<XXDense, XXPatch, true, false>(a, b, g, zdim, st, 3000, tile);
+    if (e || !slabs) return e;
+    return splitk_fold(ws, zdim, slab, dw, n, st);
+}
+extern "C" int bdetr_p16_conv2d_bwd_weight_ws(const void* x, int x_is_f16, const void* dy_bf16, float* dw,
+                                              const bdetr_conv_desc* d, int splitk, float* ws, int64_t ws_elems, void* stream) {
+    return p16_bwd_weight(x, x_is_f16, dy_bf16, dw, d, splitk, stream, ws, ws_elems);
 }
 extern "C" int bdetr_p16_conv2d_bwd_weight(const void* x_bf16, const void* dy_bf16, float* dw,
                                            const bdetr_conv_desc* d, int splitk, void* stream) {

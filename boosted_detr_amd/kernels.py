@@ -57,6 +57,36 @@ def demote_split_forward() -> None:
         check(L.bdetr_set_gemm_precision(GEMM_MIXED), "set_gemm_precision")
 
 
+# Deterministic mode (BDETR_DETERMINISTIC=1 or set_deterministic(True)): the only run-to-run variation of a training step is
+# the ORDER in which float atomics land - the split-K slices of the weight gradients and the one-launch bias-gradient column
+# sums.  In this mode the split-K launches store their slices into slabs of a workspace and a second launch folds them in a fixed
+# order (the *_ws entry points of include/bdetr.h), and column sums take the two-level fixed-order reduction: two runs of the same
+# step - eager or replayed from hipGraphs - give bit-identical weights.  Cost: one fold launch per split-K launch and the slabs'
+# round trip through HBM (reported by bench.py as `deterministic_cost`).
+import os as _os
+
+_DETERMINISTIC = [_os.environ.get("BDETR_DETERMINISTIC", "0") == "1"]
+
+
+def set_deterministic(on: bool) -> bool:
+    prev = _DETERMINISTIC[0]
+    _DETERMINISTIC[0] = bool(on)
+    return prev
+
+
+def deterministic() -> bool:
+    return _DETERMINISTIC[0]
+
+
+def _splitk_ws(rows: int, cols: int, sk: int, like: torch.Tensor):
+    """(workspace tensor, its element count) of a deterministic split-K launch, or (None, 0).  Allocated from the caching allocator on
+    the stream the launch goes to (side tasks run with the side stream current), so a later launch on that stream may reuse it."""
+    if not _DETERMINISTIC[0] or sk <= 1:
+        return None, 0
+    n = int(_lib.lib().bdetr_splitk_workspace_elems(rows, cols, sk))
+    return torch.empty(n, dtype=torch.float32, device=like.device), n
+
+
 class gemm_precision:
     """``with gemm_precision('split'): ...`` - scoped arithmetic policy (None leaves it alone)."""
 
@@ -230,7 +260,8 @@ def conv2d_bwd_weight(x, dy, g: ConvGeom, dw: Optional[torch.Tensor] = None, pre
     sk = L.bdetr_conv2d_bwd_weight_splitk(C.byref(d))
     if sk > 1 and not prezeroed:
         check(L.bdetr_zero(_p(dw), dw.numel(), _stream()), "zero")
-    check(L.bdetr_conv2d_bwd_weight(_p(x), _p(dy), _p(dw), C.byref(d), sk, _stream()), "conv2d_bwd_weight")
+    ws, n = _splitk_ws(g.K, g.R * g.S * g.C, sk, x)
+    check(L.bdetr_conv2d_bwd_weight_ws(_p(x), _p(dy), _p(dw), C.byref(d), sk, _p(ws), n, _stream()), "conv2d_bwd_weight")
     return dw
 
 
@@ -455,8 +486,8 @@ def p16_conv2d_bwd_weight(x_bf16, dy_bf16, g: ConvGeom, dw: Optional[torch.Tenso
     sk = L.bdetr_p16_conv2d_bwd_weight_splitk(C.byref(d))
     if sk > 1 and not prezeroed:
         check(L.bdetr_zero(_p(dw), dw.numel(), _stream()), "zero")
-    fn = L.bdetr_p16_conv2d_bwd_weight_xf16 if x_f16 else L.bdetr_p16_conv2d_bwd_weight
-    check(fn(_p(x_bf16), _p(dy_bf16), _p(dw), C.byref(d), sk, _stream()), "p16_conv2d_bwd_weight")
+    ws, n = _splitk_ws(g.K, g.R * g.S * g.C, sk, x_bf16)
+    check(L.bdetr_p16_conv2d_bwd_weight_ws(_p(x_bf16), int(x_f16), _p(dy_bf16), _p(dw), C.byref(d), sk, _p(ws), n, _stream()), "p16_conv2d_bwd_weight")
     return dw
 
 
@@ -468,7 +499,8 @@ def gemm_raw(I, J, R, a, lda, a_rc, b, ldb, b_rc, c, ldc, *, nb0=1, nb1=1, sa=(0
     _chk(a, b, c, bias)
     g = GemmDesc(I, J, R, nb0, nb1, _p(a), lda, sa[0], sa[1], int(a_rc), _p(b), ldb, sb[0], sb[1], int(b_rc),
                  _p(c), ldc, sc[0], sc[1], _p(bias), float(alpha), act, int(accumulate), splitk, int(grad))
-    check(_lib.lib().bdetr_gemm(C.byref(g), _stream()), "gemm")
+    ws, n = _splitk_ws(I, J, splitk, c) if ldc == J else (None, 0)
+    check(_lib.lib().bdetr_gemm_ws(C.byref(g), _p(ws), n, _stream()), "gemm")
     return c
 
 
@@ -542,7 +574,7 @@ def colsum(x2d, out=None, prezeroed=False):
     _chk(x2d, out)
     L = _lib.lib()
     rows, cols = x2d.shape
-    if prezeroed and out is not None:
+    if prezeroed and out is not None and not _DETERMINISTIC[0]:
         check(L.bdetr_colsum_accumulate(_p(x2d), rows, cols, _p(out), _stream()), "colsum_accumulate")
         return out
     if out is None:

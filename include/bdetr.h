@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define BDETR_ABI_VERSION 5
+#define BDETR_ABI_VERSION 6
 
 int         bdetr_abi_version(void);
 const char* bdetr_last_error(void);
@@ -47,10 +47,13 @@ int         bdetr_stream_priority_range(int* least, int* greatest);
  *                     ids, match indices and ReLU masks are decided by them), gradient products -
  *                     conv2d_bwd_* and GEMMs with grad != 0 - are split-bf16;
  *  BDETR_GEMM_SPLIT   gradient products split-bf16; forward products split-fp16: hi + lo fp16 halves
- *                     (11 + 11 significant bits, the lo half kept scaled by 2^11 in a second
- *                     accumulator), three products on v_mfma_f32_32x32x16_f16 - fp32-grade products
- *                     (~2^-23), but forward operands must stay below 65504 in magnitude (a larger
- *                     value yields NaN).
+ *                     (11 + 11 significant bits), three products on v_mfma_f32_32x32x16_f16 - fp32-grade
+ *                     products (~2^-22), but forward operands must stay below 65504 in magnitude (a
+ *                     larger value raises the range guard).  Since ABI 5 the pre-split (P16) operands keep
+ *                     the lo half UNSCALED in ONE accumulator (the f16 MFMA keeps subnormal operands;
+ *                     conv weights are packed as 2^8 w and the epilogue multiplies by 2^-8); only
+ *                     igemm.hip's IN-KERNEL split (stem, neck, transformer Dense: operands without a
+ *                     producer that could pre-scale them) still scales lo by 2^11 into a second accumulator.
  * The env variable BDETR_GEMM_PRECISION=fp32|bf16x3|mixed|split picks the initial value.
  * This policy is the library's ONE piece of mutable state (a mode word like a rounding mode, not data): it is thread-local,
  * so a host thread's launches are unaffected by another thread's policy, and every launch reads it once on the host at
@@ -140,6 +143,13 @@ int bdetr_conv2d_bwd_data(const float* dy, const float* w, float* dx,
 int bdetr_conv2d_bwd_weight(const float* x, const float* dy, float* dw,
                             const bdetr_conv_desc* d, int splitk, void* stream);
 int bdetr_conv2d_bwd_weight_splitk(const bdetr_conv_desc* d);
+/* Deterministic split-K (ABI 6): the same launch, but every r-slice STORES its partial dw into its own slab of the caller's
+ * workspace `ws` (16-byte aligned, ws_elems >= bdetr_splitk_workspace_elems(K, R*S*C, splitk) floats) and a second launch adds
+ * the slabs to dw in the fixed order z = 0, 1, ...: two runs give bit-identical gradients.  ws == NULL: the atomic form above.
+ * Replaces the same Keras autodiff call sites (backbone.py:37-38,57); the reference itself (TF on CPU) is deterministic. */
+int bdetr_conv2d_bwd_weight_ws(const float* x, const float* dy, float* dw,
+                               const bdetr_conv_desc* d, int splitk, float* ws, int64_t ws_elems, void* stream);
+int64_t bdetr_splitk_workspace_elems(int64_t I, int64_t J, int splitk);
 
 /* ------------------------------------------------------------------------
  * Pre-split ("P16") operand path of the same convolutions - csrc/sgemm.hip.  Replaces the same reference
@@ -234,6 +244,9 @@ int bdetr_p16_conv2d_bwd_weight(const void* x_bf16, const void* dy_bf16, float* 
  * write a bf16 copy of an activation at all: 4 bytes per element of HBM traffic and of saved-activation memory less. */
 int bdetr_p16_conv2d_bwd_weight_xf16(const void* x_f16, const void* dy_bf16, float* dw,
                                      const bdetr_conv_desc* d, int splitk, void* stream);
+/* deterministic split-K form of the two above (see bdetr_conv2d_bwd_weight_ws); x_is_f16 selects the xf16 operand flavour */
+int bdetr_p16_conv2d_bwd_weight_ws(const void* x, int x_is_f16, const void* dy_bf16, float* dw,
+                                   const bdetr_conv_desc* d, int splitk, float* ws, int64_t ws_elems, void* stream);
 
 /* strided-batched GEMM - tf Dense / tf.linalg.matmul call sites
  * (transformers.py:41-48,62-65,86,97,101,174-177; prediction_heads.py:40-43,106-110,175-179)
@@ -252,6 +265,9 @@ typedef struct {
     int grad;                /* != 0: a gradient (backward) product - see BDETR_GEMM_MIXED */
 } bdetr_gemm_desc;
 int bdetr_gemm(const bdetr_gemm_desc* g, void* stream);
+/* bdetr_gemm with a deterministic split-K reduction (g->splitk > 1, dense C: ldc == J): slabs in `ws`
+ * (>= bdetr_splitk_workspace_elems(I, J, splitk) floats), fixed-order fold into C (C += sum of the slices).  ws == NULL: bdetr_gemm. */
+int bdetr_gemm_ws(const bdetr_gemm_desc* g, float* ws, int64_t ws_elems, void* stream);
 /* n (1..4) independent GEMMs that share J, R, leading dimensions, operand flavours and epilogue flags
  * (their pointers, bias and row count I may differ) in ONE launch - the Q/K/V projections of an
  * attention block (transformers.py:68-70) and their input gradients.  No batching / split-K inside. */

@@ -54,6 +54,17 @@ def test_linear_bwd(cuda, M, K, O):
     acc = torch.zeros(O).cuda()
     k.colsum(dev(dy), out=acc, prezeroed=True)          # one-launch form: float atomics into a zero-filled gradient slot
     close(acc, dy.double().sum(0), rtol=1e-5)
+    prev = k.set_deterministic(True)                    # bdetr_gemm_ws + the two-level column sum: bit-identical twice
+    try:
+        d1, d2 = k.linear_bwd_weight(dev(dy), dev(x)), k.linear_bwd_weight(dev(dy), dev(x))
+        a1, a2 = torch.zeros(O).cuda(), torch.zeros(O).cuda()
+        k.colsum(dev(dy), out=a1, prezeroed=True)
+        k.colsum(dev(dy), out=a2, prezeroed=True)
+    finally:
+        k.set_deterministic(prev)
+    close(d1, dy.double().T @ x.double())
+    close(a1, dy.double().sum(0), rtol=1e-5)
+    assert torch.equal(d1, d2) and torch.equal(a1, a2)
 
 
 def test_gemm_batched_attention_shapes(cuda):
@@ -134,6 +145,13 @@ def test_conv_fwd_bwd(cuda, N, H, W, C, K, R, stride, pad):
         close(dx2, base.double() + xt.grad.permute(0, 2, 3, 1))
     dw = k.conv2d_bwd_weight(dev(x), dev(dyn), g)
     close(dw, wt.grad.permute(0, 2, 3, 1), rtol=5e-5)
+    prev = k.set_deterministic(True)                    # split-K through slabs + a fixed-order fold (bdetr_conv2d_bwd_weight_ws)
+    try:
+        d1, d2 = k.conv2d_bwd_weight(dev(x), dev(dyn), g), k.conv2d_bwd_weight(dev(x), dev(dyn), g)
+    finally:
+        k.set_deterministic(prev)
+    close(d1, wt.grad.permute(0, 2, 3, 1), rtol=5e-5)
+    assert torch.equal(d1, d2)
 
 
 # ---------------------------------------------------------------- norms

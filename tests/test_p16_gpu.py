@@ -116,6 +116,18 @@ def p16_conv_case(N, H, W, C, K, R, stride, pad, accumulate=True):
     close(k.p16_conv2d_bwd_weight(xb, dyb, g), wtt.grad.permute(0, 2, 3, 1), rtol=6e-5)
     # the same from the FORWARD's f16 pair of x (converted to bf16 pairs inside the kernel): what the training step uses
     close(k.p16_conv2d_bwd_weight(xf, dyb, g, x_f16=True), wtt.grad.permute(0, 2, 3, 1), rtol=6e-5)
+    # deterministic split-K (bdetr_p16_conv2d_bwd_weight_ws): slabs + fixed-order fold - the same values, and bit-identical twice
+    prev = k.set_deterministic(True)
+    try:
+        d1 = k.p16_conv2d_bwd_weight(xf, dyb, g, x_f16=True)
+        d2 = k.p16_conv2d_bwd_weight(xf, dyb, g, x_f16=True)
+        base = dev(rnd(K, R, R, C, seed=12))
+        d3 = k.p16_conv2d_bwd_weight(xb, dyb, g, dw=base.clone(), prezeroed=True)       # "+=" onto a running sum, like the atomics
+    finally:
+        k.set_deterministic(prev)
+    close(d1, wtt.grad.permute(0, 2, 3, 1), rtol=6e-5)
+    assert torch.equal(d1, d2)
+    close(d3, base.double().cpu() + wtt.grad.permute(0, 2, 3, 1), rtol=6e-5)
 
 
 @pytest.mark.parametrize("N,H,W,C,K,R,stride,pad", P16_CONVS + P16_BIG_CONVS)

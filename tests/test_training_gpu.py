@@ -358,11 +358,27 @@ def test_momentum_survives_a_freeze_unfreeze_cycle(cuda):
     assert len(m.optimizer.vars) < 200 and torch.equal(m.optimizer.mom_views[j], mom)
 
 
-def test_graph_replayed_steps_equal_eager_steps(cuda):
-    """Model.use_graph: the third step on an input signature is captured as a hipGraph and later steps replay it.  With
+@pytest.fixture
+def deterministic():
+    """BDETR_DETERMINISTIC mode for one test: split-K slices go through slabs + a fixed-order fold, column sums take the two-level
+    reduction (kernels.set_deterministic) - two runs of one step give bit-identical weights."""
+    from boosted_detr_amd import kernels as K
+    prev = K.set_deterministic(True)
+    yield
+    K.set_deterministic(prev)
+
+
+def _same_weights(a: dict, b: dict):
+    bad = [k for k in a if not np.array_equal(a[k], b[k])]
+    return bad
+
+
+def test_graph_replayed_steps_equal_eager_steps(cuda, deterministic):
+    """Model.use_graph: the third step on an input signature is captured as a chain of hipGraphs and later steps replay it.  With
     dropout on (masks keyed by a per-step seed kept in HBM) and a cosine learning-rate schedule (rate staged in HBM per
-    step), six replayed steps must track six eagerly enqueued ones: same losses, same weights (split-K atomics make any two
-    runs differ in the last bits, and a 2-image toy trajectory amplifies that - hence the loose late-step bound)."""
+    step), six replayed steps must EQUAL six eagerly enqueued ones: in deterministic mode (no float atomics) every loss and every
+    weight is the same to the last bit - a stale dropout seed, learning rate or input in a replayed graph cannot hide in a
+    tolerance (round 3 compared to 20 % because of the atomics)."""
     from boosted_detr_amd.engine import to_device
     from boosted_detr_amd.training import SGD, CosineDecayRestarts
     from oracle import detr_oracle as O
@@ -373,41 +389,35 @@ def test_graph_replayed_steps_equal_eager_steps(cuda):
                            "num_objects": to_device(b["num_objects"], torch.int32)}
     batches = [dev_batch(host), dev_batch(small_batch(seed=21)[1])]
     runs = {}
-    for graph in (False, True):
+    for graph in (False, True, "again"):
         m = small_model(dropout=0.1)
         m.compile(optimizer=SGD(CosineDecayRestarts(1e-3, 10, m_mul=.95, alpha=.1), momentum=.9, nesterov=True, clipnorm=.1))
         m.forward_backward(batches[0])
         m.set_weights_dict(params)
-        m.use_graph = graph
+        m.use_graph = graph is True
         losses = [m.logs_to_host(m.train_step(batches[i % 2]))["loss"] for i in range(8)]
-        assert (len(m._graphs) == 1) == graph and m.steps_done == 8 and m.optimizer.iterations == 8
+        assert (len(m._graphs) == 1) == (graph is True) and m.steps_done == 8 and m.optimizer.iterations == 8
         runs[graph] = (losses, m.get_weights_dict())
-    le, lg = runs[False][0], runs[True][0]
+    le, lg, le2 = runs[False][0], runs[True][0], runs["again"][0]
     assert all(np.isfinite(lg))
-    # Two model instances already differ after one step (float atomics of the split-K weight gradients, which gradients
-    # land directly in the flat buffer): measured over ten EAGER instances the second loss takes a handful of values within
-    # 3e-5 of each other (113.5985 ... 113.6023), and this 2-image toy amplifies that to 4e-4 of the third.  Same numbers
-    # while that is still noise of that size:
-    assert all(abs(a - b) <= 1e-4 * abs(a) for a, b in zip(le[:2], lg[:2])), (le, lg)
-    assert all(abs(a - b) <= 3e-3 * abs(a) for a, b in zip(le[:4], lg[:4])), (le, lg)
-    assert all(abs(a - b) <= 0.2 * abs(a) for a, b in zip(le, lg)), (le, lg)       # (late steps: the toy's own run-to-run spread, see above)
-    assert lg[2] != lg[4]                                                                    # fresh masks / inputs per replay, not a frozen step
+    assert le == le2 and not _same_weights(runs[False][1], runs["again"][1])           # the mode itself: two eager runs are identical
+    assert le == lg, (le, lg)                                                          # every loss, bit for bit
+    assert not _same_weights(runs[False][1], runs[True][1]), _same_weights(runs[False][1], runs[True][1])[:5]
+    assert lg[2] != lg[4]                                                              # fresh masks / inputs per replay, not a frozen step
 
 
-def test_unsynchronised_graph_replays_stay_finite_and_track_eager_steps(cuda):
+def test_unsynchronised_graph_replays_equal_eager_steps(cuda, deterministic):
     """Back-to-back replays with NO host read in between (the way bench.py and a training loop without per-step logging run):
     on ROCm 7.2 the second replay of a graph without a stream synchronisation in between handed NaN gradients to the optimizer
-    unless the runtime's pre-built-packet path is off (boosted_detr_amd/__init__.py sets DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 and
-    Model refuses graphs when that came too late).  Twelve unsynchronised steps must leave finite weights, no guard redo, and a
-    loss that fell like the eager run's (this 2-image toy amplifies the split-K atomics' last-bit differences tenfold per step: two
-    EAGER runs agree to 3e-5 at the fourth step, 2e-3 at the fifth and differ by up to 13 % from the eighth on - measured - so the
-    trajectories are only compared loosely)."""
+    unless the runtime's pre-built-packet path is off (boosted_detr_amd.enable_graph_replay; Model refuses graphs when that came
+    too late).  Twelve unsynchronised replayed steps must leave exactly the weights of twelve eager steps (deterministic mode:
+    bit for bit), no guard redo."""
     import boosted_detr_amd
     from boosted_detr_amd import kernels as K
     from boosted_detr_amd.engine import to_device
     from boosted_detr_amd.training import SGD
     from oracle import detr_oracle as O
-    assert boosted_detr_amd.graph_replay_is_safe(), "the test session initialised HIP before importing boosted_detr_amd"
+    assert boosted_detr_amd.graph_replay_is_safe(), "the test session initialised HIP before boosted_detr_amd.enable_graph_replay()"
     cfg, host = small_batch()
     params = O.make_params(cfg, seed=1)
     batch = {"image": to_device(host["image"]), "category": to_device(host["category"], torch.int32),
@@ -430,10 +440,10 @@ def test_unsynchronised_graph_replays_stay_finite_and_track_eager_steps(cuda):
         assert (len(m._graphs) == 1) == graph
         assert m.range_redos == 0 and int(K.overflow_flag().item()) == 0, (graph, m.range_redos)
         assert all(bool(torch.isfinite(v.value).all()) for v in m.variables), graph
-        final[graph] = (m.logs_to_host({"loss": first})["loss"], m.logs_to_host(logs)["loss"])
-    assert abs(final[True][0] - final[False][0]) <= 1e-4 * abs(final[False][0]), final          # the first step: same numbers
-    assert all(f[1] < 0.8 * f[0] for f in final.values()), final                                 # both trained
-    assert 0.6 < final[True][1] / final[False][1] < 1 / 0.6, final
+        final[graph] = (m.logs_to_host({"loss": first})["loss"], m.logs_to_host(logs)["loss"], m.get_weights_dict())
+    assert final[True][0] == final[False][0] and final[True][1] == final[False][1], (final[True][:2], final[False][:2])
+    assert not _same_weights(final[False][2], final[True][2]), _same_weights(final[False][2], final[True][2])[:5]
+    assert final[False][1] < 0.8 * final[False][0]                                                # and it trained
 
 
 def test_non_finite_gradient_raises_the_guard_and_applies_nothing(cuda):
