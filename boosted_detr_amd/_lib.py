@@ -109,6 +109,7 @@ SIGNATURES = {
     "bdetr_bn_stats": (I, [P, L, I, P, P, I, F, F, I, P, P, P, P, P, P, P]),
     "bdetr_flag_nonfinite": (I, [P, L, P, P]),
     "bdetr_flag_snapshot": (I, [P, P, P, I, P]),
+    "bdetr_debug_checksum": (I, [P, L, P, P, P, I, U64, P]),
     "bdetr_bn_stats_fold_rows": (I, []),
     "bdetr_bn_stats_frozen": (I, [P, P, I, F, P, P, P]),
     "bdetr_bn_apply": (I, [P, P, P, P, P, P, I, P, L, I, P]),

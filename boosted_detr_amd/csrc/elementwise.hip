@@ -228,6 +228,39 @@ extern "C" int bdetr_flag_snapshot(const int* flag, int* ordinal, int* host_ring
     return bdetr_launch_status("flag_snapshot");
 }
 
+// Diagnostic (tools/graph_segment_checksums.py): an ORDER-INDEPENDENT fingerprint of a buffer - the wrapping sum of its bit patterns
+// and the count of its non-finite elements - appended to a device-resident log behind a device-resident cursor, so that the launch
+// can be captured into a hipGraph segment and every replay appends its own entry.  Two launches: the grid adds into scratch[0..1]
+// with integer atomics, one lane moves scratch to log[cursor++] and clears it.
+namespace {
+__global__ __launch_bounds__(256) void debug_checksum_kernel(const float* __restrict__ x, int64_t n, unsigned long long* __restrict__ scratch) {
+    unsigned long long s = 0, bad = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const unsigned u = __float_as_uint(x[i]);
+        s += u;
+        bad += ((u & 0x7F800000u) == 0x7F800000u) ? 1ull : 0ull;
+    }
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); bad += __shfl_xor(bad, o, 64); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&scratch[0], s); atomicAdd(&scratch[1], bad); }
+}
+__global__ void debug_checksum_commit_kernel(unsigned long long* __restrict__ scratch, unsigned long long* __restrict__ log, int* __restrict__ cursor, int cap, unsigned long long tag) {
+    if (threadIdx.x == 0) {
+        const int c = *cursor;
+        if (c < cap) { log[3 * c] = scratch[0]; log[3 * c + 1] = scratch[1]; log[3 * c + 2] = tag; }
+        *cursor = c + 1;
+        scratch[0] = 0; scratch[1] = 0;
+    }
+}
+}  // namespace
+extern "C" int bdetr_debug_checksum(const float* x, int64_t n, uint64_t* scratch, uint64_t* log, int* cursor, int cap, uint64_t tag, void* stream) {
+    BDETR_CHECK_ARG(x && scratch && log && cursor && n > 0 && cap > 0, "bdetr_debug_checksum: bad arguments");
+    const int grid = (int)(n / 256 / 8 > 2048 ? 2048 : (n / 256 / 8 < 1 ? 1 : n / 256 / 8));
+    hipLaunchKernelGGL(debug_checksum_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, n, reinterpret_cast<unsigned long long*>(scratch));
+    hipLaunchKernelGGL(debug_checksum_commit_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<unsigned long long*>(scratch),
+                       reinterpret_cast<unsigned long long*>(log), cursor, cap, (unsigned long long)tag);
+    return bdetr_launch_status("debug_checksum");
+}
+
 extern "C" int bdetr_flag_nonfinite(const float* x, int64_t n, int* flag, void* stream) {
     BDETR_CHECK_ARG(x && flag && n > 0, "bdetr_flag_nonfinite: bad arguments");
     hipLaunchKernelGGL(flag_nonfinite_kernel, dim3(ew_grid(n, 256, 4)), dim3(256), 0, (hipStream_t)stream, x, n, flag);

@@ -243,7 +243,10 @@ class Tape:
                 else:
                     grads[key] = g
             if _CAPTURE[0] is not None:
-                _CAPTURE[0].maybe_cut()            # segmented graph capture: cut between tape nodes once enough side tasks are pending
+                # segmented graph capture: cut between tape nodes once enough side tasks are pending
+                _CAPTURE[0].maybe_cut(next((g for g in gins if isinstance(g, torch.Tensor)), None) if _DEBUG_LOG[0] is not None else None)
+            elif _DEBUG_LOG[0] is not None and _DEBUG_LOG[0].eager_pending >= SegmentedCapture.SIDE_TASKS_PER_SEGMENT:
+                _debug_cut(next((g for g in gins if isinstance(g, torch.Tensor)), None))
         return grads
 
 
@@ -327,6 +330,53 @@ class on_side_stream:
 # to M_{i+1}); tensors that cross (the operands of the side tasks) are kept alive by the deferred closures until the capture ends.
 
 
+class DebugLog:
+    """Diagnostic of the graph-replay path (tools/graph_segment_checksums.py): order-independent fingerprints of the live flat gradient
+    buffer (and of the activation gradient that crosses a cut) appended to a device-resident log at every segment boundary of the
+    backward pass - captured INTO the segments under use_graph, enqueued at the same points of an eager step (which counts side
+    tasks the way SegmentedCapture.maybe_cut does).  Needs a stream-ordered step: BDETR_SIDE_STREAM=0 / BDETR_GRAPH_SIDE=0."""
+    TAGS = {"A": 1, "M": 2, "S": 3}
+
+    def __init__(self, cap: int = 1 << 14):
+        dev = device()
+        self.cap = cap
+        self.scratch = torch.zeros(2, dtype=torch.int64, device=dev)
+        self.log = torch.zeros(cap * 3, dtype=torch.int64, device=dev)
+        self.cursor = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.eager_pending = 0
+
+    def emit(self, kind: str, t: Optional[torch.Tensor]) -> None:
+        if t is None or not isinstance(t, torch.Tensor) or t.numel() == 0 or t.dtype != torch.float32 or not t.is_contiguous():
+            t = self.scratch.view(torch.float32)[:1]           # keep the entry count the same in both modes
+        from . import _lib
+        _lib.check(_lib.lib().bdetr_debug_checksum(t.data_ptr(), t.numel(), self.scratch.data_ptr(), self.log.data_ptr(), self.cursor.data_ptr(),
+                                                   self.cap, self.TAGS[kind], K._stream()), "debug_checksum")
+
+    def entries(self):
+        torch.cuda.synchronize()
+        n = min(int(self.cursor.item()), self.cap)
+        a = self.log[: 3 * n].view(n, 3).cpu().numpy()
+        inv = {v: k for k, v in self.TAGS.items()}
+        return [(inv.get(int(r[2]), "?"), int(r[0]) & 0xFFFFFFFFFFFFFFFF, int(r[1])) for r in a]
+
+
+_DEBUG_LOG: List[Optional[DebugLog]] = [None]
+
+
+def set_debug_log(log: Optional[DebugLog]) -> None:
+    _DEBUG_LOG[0] = log
+
+
+def _debug_cut(extra) -> None:
+    """Eager twin of SegmentedCapture.cut() for the debug log: the three entries a captured cut appends."""
+    log = _DEBUG_LOG[0]
+    from . import ops
+    log.emit("A", extra)
+    log.emit("M", ops._live_flat_grad[0])
+    log.emit("S", ops._live_flat_grad[0])
+    log.eager_pending = 0
+
+
 class SegmentedCapture:
     SIDE_TASKS_PER_SEGMENT = int(_os.environ.get("BDETR_GRAPH_SEG", "10"))
 
@@ -377,21 +427,30 @@ class SegmentedCapture:
             try:
                 for fn in self.pending:
                     fn()
+                if _DEBUG_LOG[0] is not None:
+                    from . import ops
+                    _DEBUG_LOG[0].emit("S", ops._live_flat_grad[0])
             finally:
                 K.set_launch_stream(prev)
         self.sides.append(g)
         self.done.extend(self.pending)
         self.pending = []
 
-    def cut(self) -> None:
+    def cut(self, extra=None) -> None:
         """Close the open main segment, capture its side tasks, open the next main segment."""
+        if _DEBUG_LOG[0] is not None:
+            from . import ops
+            _DEBUG_LOG[0].emit("A", extra)
+            _DEBUG_LOG[0].emit("M", ops._live_flat_grad[0])
+            if not self.pending:
+                _DEBUG_LOG[0].emit("S", ops._live_flat_grad[0])       # (no side graph for this segment: keep three entries per cut)
         self.end_main()
         self.capture_side()
         self.begin_main()
 
-    def maybe_cut(self) -> None:
+    def maybe_cut(self, extra=None) -> None:
         if len(self.pending) >= self.SIDE_TASKS_PER_SEGMENT:
-            self.cut()
+            self.cut(extra)
 
     def replay(self, side) -> None:
         """mains[i] on the current stream, sides[i] on `side` behind an event; the LAST main segment (optimizer) waits for the side stream.
@@ -424,6 +483,8 @@ def side_task(fn, *keep) -> None:
     if cap is not None:
         cap.pending.append(fn)
         return
+    if _DEBUG_LOG[0] is not None:
+        _DEBUG_LOG[0].eager_pending += 1
     with on_side_stream(*keep):
         fn()
 

@@ -12,6 +12,7 @@ from __future__ import annotations
 import glob
 import math
 import os
+import sys
 import time
 from typing import Dict, Iterable, List, Optional
 
@@ -82,7 +83,16 @@ class SGD:
         dev = device()
         # momentum survives a rebuild for every variable that stays trainable (Keras keeps one slot variable per weight:
         # freezing the backbone and unfreezing it later, Boosted_DETR_COCO.ipynb cell 30, does not reset the others' velocity)
-        old_mom = {id(v): m for v, m in zip(getattr(self, "vars", []), getattr(self, "mom_views", []))}
+        # The velocity also survives a freeze -> unfreeze cycle: a variable that leaves the trainable set parks a copy of its velocity on
+        # itself (v._momentum) and gets it back when it re-enters (keyed by the Variable object, not by id(): ids are reused after garbage
+        # collection).
+        old_mom = {}
+        for v, m in zip(getattr(self, "vars", []), getattr(self, "mom_views", [])):
+            old_mom[id(v)] = (v, m)
+        staying = {id(v) for v in variables}
+        for k, (v, m) in old_mom.items():
+            if k not in staying:
+                v._momentum = m.clone()
         self.release()
         self.vars = list(variables)
         sizes = [v.value.numel() for v in self.vars]
@@ -92,8 +102,12 @@ class SGD:
         self.grad_views = [self.flat_grad[int(o): int(o) + s].view(v.value.shape) for o, s, v in zip(offs[:-1], sizes, self.vars)]
         mom_views = [self.flat_mom[int(o): int(o) + s] for o, s in zip(offs[:-1], sizes)]
         for v, m in zip(self.vars, mom_views):
-            if id(v) in old_mom and old_mom[id(v)].numel() == m.numel():
-                m.copy_(old_mom[id(v)])
+            have = old_mom.get(id(v))
+            if have is not None and have[0] is v and have[1].numel() == m.numel():
+                m.copy_(have[1])
+            elif getattr(v, "_momentum", None) is not None and v._momentum.numel() == m.numel():
+                m.copy_(v._momentum)                 # re-entering the trainable set: Keras kept its slot variable all along
+            v._momentum = None
         self.mom_views = mom_views
         ptrs = np.zeros((len(self.vars), 3), np.uint64)
         for i, v in enumerate(self.vars):
@@ -446,8 +460,22 @@ class Model(Layer):
         self._guard_count = 0
         self._guard_pending: List[tuple] = []      # (step's batch, its ordinal in the pinned flag log, the event recorded behind it)
         self._guard_was = None
-        self.use_graph = os.environ.get("BDETR_GRAPH", "0") == "1"      # capture train_step as a hipGraph (see _graph_step)
         self._graphs, self._graph_warm = {}, {}
+        self.use_graph = os.environ.get("BDETR_GRAPH", "0") == "1"      # capture train_step as a hipGraph (see _graph_step)
+        self.range_redo_streak = 0       # consecutive guarded steps that had to be redone (see _guard_redo: persistent demotion)
+
+    @property
+    def use_graph(self) -> bool:
+        return self.__dict__.get("_use_graph", False)
+
+    @use_graph.setter
+    def use_graph(self, on: bool) -> None:
+        # Opting in to graph replay is also the opt-in to the runtime switch it needs (boosted_detr_amd.enable_graph_replay: a no-op
+        # once HIP is up - _graph_signature then refuses to capture and the steps stay eager, with one warning).
+        if on:
+            from . import enable_graph_replay
+            enable_graph_replay()
+        self.__dict__["_use_graph"] = bool(on)
 
     # -- Keras bookkeeping -----------------------------------------------------------------
     def add_loss(self, loss) -> None:
@@ -526,6 +554,8 @@ class Model(Layer):
                 from . import engine as _engine
                 if _engine._CAPTURE[0] is not None:
                     _engine._CAPTURE[0].cut()        # segmented capture: close the backward's last segment (its side tasks need this step's sinks)
+                elif _engine._DEBUG_LOG[0] is not None:
+                    _engine._debug_cut(None)         # (diagnostic twin of that cut in an eager step)
             self._kept_tape = tape if keep_tape else None
         finally:
             K.set_launch_stream(prev)
@@ -674,6 +704,7 @@ class Model(Layer):
         return logs
 
     GUARD_LAG = 2        # steps between a snapshot and the host's look at it
+    GUARD_DEMOTE_AFTER = 3   # consecutive redos after which the policy falls back to 'mixed' for good (_guard_redo)
     GUARD_RING = 8       # per-step entries of the pinned log (> GUARD_LAG + 1, the most that are ever pending)
 
     def _guard_snapshot(self) -> None:
@@ -704,13 +735,16 @@ class Model(Layer):
             return logs                            # (no guarded step has run yet)
         ev = self._guard_events[self._guard_launched % self.GUARD_RING]
         ev.record()
-        self._guard_pending.append((data, self._guard_launched, ev))
+        # The batch is kept BY REFERENCE until its snapshot has been examined (GUARD_LAG + 1 steps): a redo trains on these tensors
+        # again, so an input pipeline must not overwrite them in place before then.  Their version counters are noted here and
+        # checked in _guard_redo - a reused buffer is an error there, not a silently different batch.
+        self._guard_pending.append((data, self._guard_launched, ev, tuple((k, v._version) for k, v in data.items() if isinstance(v, torch.Tensor))))
         return self._guard_resolve(logs, 0 if force else self.GUARD_LAG)
 
     def _guard_resolve(self, logs, keep: int):
         host = self._guard_host
         while len(self._guard_pending) > keep:
-            _, k, e = self._guard_pending[0]
+            _, k, e = self._guard_pending[0][:3]
             if int(host[0]) < k:                     # (not landed yet: normally it has, GUARD_LAG steps later)
                 e.synchronize()
                 if int(host[0]) < k:
@@ -718,6 +752,7 @@ class Model(Layer):
             if int(host[1 + k % self.GUARD_RING]) != 0:
                 return self._guard_redo(0, logs)
             self._guard_pending.pop(0)
+            self.range_redo_streak = 0               # a guarded step went through clean
         return logs
 
     def guard_flush(self):
@@ -730,6 +765,11 @@ class Model(Layer):
         import sys
         torch.cuda.synchronize()                             # rare: every later attempt has finished (none of them applied an update)
         batches = [p[0] for p in self._guard_pending[first_bad:]]
+        for p in self._guard_pending[first_bad:]:
+            stale = [k for k, ver in (p[3] if len(p) > 3 else ()) if p[0][k]._version != ver]
+            if stale:
+                raise RuntimeError(f"range guard: the batch of step ordinal {p[1]} must be redone, but its tensors {stale} were modified in place since "
+                                   f"(an input pipeline has to leave a batch untouched for GUARD_LAG + 1 = {self.GUARD_LAG + 1} steps under the 'split' policy)")
         self._guard_pending = []
         K.overflow_flag().zero_()
         n = len(batches)
@@ -740,12 +780,22 @@ class Model(Layer):
         print(f"[boosted_detr_amd] step {self.steps_done}: the split-fp16 forward left its range (|x| >= 65504) or went non-finite; "
               f"no update was applied since - redoing {n} batch(es) on the exact-fp32 forward", file=sys.stderr)
         keep, self.train_gemm_precision = self.train_gemm_precision, "mixed"
+        keep_graph, self.use_graph = self.use_graph, False   # the redone batches run eagerly: no fresh capture (and no second private pool) mid-training
         try:
             for d in batches:
                 logs = self._train_step_once(d)
         finally:
             self.train_gemm_precision = keep
+            self.use_graph = keep_graph
         K.overflow_flag().zero_()                            # (bn_stats may have re-raised it for a genuinely non-finite batch statistic)
+        # A model whose weights or activations sit outside the f16 pair's range for good (e.g. a conv weight beyond 65504 / P16_W_SCALE)
+        # would run, skip and redo EVERY step - three times the cost behind a stderr line.  After GUARD_DEMOTE_AFTER redos without a
+        # clean guarded step in between, the exact-fp32 forward ('mixed') becomes the model's policy and says so once.
+        self.range_redo_streak += 1
+        if self.range_redo_streak >= self.GUARD_DEMOTE_AFTER and self.train_gemm_precision == "split":
+            self.train_gemm_precision = "mixed"
+            print(f"[boosted_detr_amd] {self.range_redo_streak} consecutive range-guard redos: train_gemm_precision is now 'mixed' (exact-fp32 forward) "
+                  "for the rest of this model's life; set it back to 'split' by hand if the cause was transient", file=sys.stderr)
         return logs
 
     def _train_step_once(self, data: dict) -> Dict[str, torch.Tensor]:

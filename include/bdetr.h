@@ -306,6 +306,10 @@ int bdetr_flag_nonfinite(const float* x, int64_t n, int* flag, void* stream);
  * and then the ordinal at host_ring[0], so a host that finds host_ring[0] >= k may read step k's entry (Model._guard_poll).
  * Capturable: it belongs to the step (the last launch of its optimizer segment), nothing is enqueued between steps. */
 int bdetr_flag_snapshot(const int* flag, int* ordinal, int* host_ring, int ring_len, void* stream);
+/* Diagnostic of the hipGraph replay path (no reference counterpart; tools/graph_segment_checksums.py): appends
+ * {wrapping sum of x's bit patterns, count of non-finite elements, tag} to log[3 * (*cursor)++] (device memory, `cap` entries;
+ * scratch: two zeroed device words).  Order-independent, stream-ordered, capturable: every replay of a segment appends an entry. */
+int bdetr_debug_checksum(const float* x, int64_t n, uint64_t* scratch, uint64_t* log, int* cursor, int cap, uint64_t tag, void* stream);
 /* fold_ws (optional): 2*C*bdetr_bn_stats_fold_rows() floats; lets bn_stats pre-reduce thousands of
  * epilogue partial rows with a wide grid before the fp64 finalise */
 int bdetr_bn_stats_fold_rows(void);

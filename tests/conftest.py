@@ -7,7 +7,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import boosted_detr_amd  # noqa: E402,F401  (sets the hipGraph runtime switch before any test initialises HIP; see its __init__)
+import boosted_detr_amd  # noqa: E402
+
+boosted_detr_amd.enable_graph_replay()      # before any test initialises HIP: the graph-replay tests need the runtime switch (see the package's __init__)
 
 
 def pytest_configure(config):

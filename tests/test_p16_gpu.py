@@ -298,3 +298,24 @@ def test_masked_accumulate_also_reduces_the_previous_units_batchnorm_backward(cu
     got = k.bn_bwd_p16(dx.view(rows, C), bits, y, mean, rstd, gamma, True, False, beta=beta, want_fp32=True, out_p16=2, pre=parts)
     close(got[2], ref[2], rtol=1e-5); close(got[3], ref[3], rtol=1e-5)          # dgamma, dbeta
     close(got[1], ref[1], rtol=1e-5)                                             # dx of the BatchNorm
+
+
+@pytest.mark.parametrize("rms", [1e-3, 1e-5])
+def test_p16_forward_on_small_activations(cuda, rms):
+    """The f16 pair keeps its lo half UNSCALED (p16.h): for |x| < 2^-3 the pair's error is absolute, 2^-25, not relative.  An activation
+    tensor whose RMS is far below 1 therefore loses relative accuracy: bound 2^-25 / RMS per element, and - errors of the K products
+    adding incoherently - about that over the output's RMS too.  RMS 1e-3 (3e-5 per element): the forward product still meets 1e-4 of
+    the output's scale, 10x inside the 1e-3 parity bar; RMS 1e-5: 3e-3 per element, the bound below is what DESIGN.md section 4 states
+    (BatchNorm / LayerNorm outputs, the only forward operands of the training step, have RMS ~1)."""
+    from boosted_detr_amd import kernels as k
+    N, H, W, C, K, R = 2, 20, 20, 256, 128, 3
+    x, w = rnd(N, H, W, C, seed=1, scale=rms), rnd(K, R, R, C, seed=2, scale=(R * R * C) ** -0.5)
+    g = k.ConvGeom(N, H, W, C, K, R, R, 1, 1)
+    xf, _ = k.p16_pack(dev(x), want_bf16=False)
+    wf, _ = k.p16_pack_conv_weights(dev(w), want_bwd=False)
+    y = k.p16_conv2d_fwd(xf, wf, None, g, 0)
+    y = y[0] if isinstance(y, tuple) else y
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
+    err = (y.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    bound = max(2e-5, 4 * 2.0 ** -25 / rms)
+    assert err <= bound, (err, bound)

@@ -352,10 +352,18 @@ def test_momentum_survives_a_freeze_unfreeze_cycle(cuda):
     i = [id(x) for x in m.optimizer.vars].index(id(v))
     mom = m.optimizer.mom_views[i].clone()
     assert float(mom.abs().max()) > 0
+    fz = next(x for x in m.optimizer.vars if x.name.startswith(m.EncoderBackbone.scope))          # a backbone weight that is about to be frozen
     m.EncoderBackbone.trainable = False
     m.forward_backward(batch)                                          # rebuilds the flat buffers for the smaller set
     j = [id(x) for x in m.optimizer.vars].index(id(v))
     assert len(m.optimizer.vars) < 200 and torch.equal(m.optimizer.mom_views[j], mom)
+    # ... and of a variable that was frozen and comes back (Keras keeps its slot variable across the freeze)
+    assert fz._momentum is not None and float(fz._momentum.abs().max()) > 0
+    parked = fz._momentum.clone()
+    m.EncoderBackbone.trainable = True
+    m.forward_backward(batch)
+    k = [id(x) for x in m.optimizer.vars].index(id(fz))
+    assert torch.equal(m.optimizer.mom_views[k], parked) and fz._momentum is None
 
 
 @pytest.fixture
