@@ -160,7 +160,7 @@ def step_hbm(ms_per_step):
 ENV_REFUSED = ("BDETR_SGEMM_DBG", "BDETR_GRAPH_UNSAFE")
 ENV_RECORDED = ("BDETR_STILE", "BDETR_TILE", "BDETR_P16", "BDETR_BN_FUSE", "BDETR_LAZY_SKIP", "BDETR_WGRAD_WANT", "BDETR_WGRAD_MINSTAGES",
                 "BDETR_GEMM_PRECISION", "BDETR_SIDE_STREAM", "BDETR_SIDE_PRIORITY", "BDETR_GRAPH", "BDETR_DP_OVERLAP", "BDETR_DP_FORCE", "BDETR_LIB",
-                "BDETR_CXXFLAGS", "BDETR_FORCE_DEVICE", "BDETR_DIST_BACKEND", "BDETR_CPU_THREADS", "BDETR_HCONV", "BDETR_ATTN_SPLIT", "BDETR_WGRAD_XF16", "BDETR_BF16_3X3", "BDETR_WGRAD_1X1_TILE", "BDETR_GRAPH_SEG", "BDETR_GRAPH_SIDE", "BDETR_DETERMINISTIC", "BDETR_ROWCHAIN")
+                "BDETR_CXXFLAGS", "BDETR_FORCE_DEVICE", "BDETR_DIST_BACKEND", "BDETR_CPU_THREADS", "BDETR_HCONV", "BDETR_ATTN_SPLIT", "BDETR_WGRAD_XF16", "BDETR_BF16_3X3", "BDETR_WGRAD_1X1_TILE", "BDETR_GRAPH_SEG", "BDETR_GRAPH_SIDE", "BDETR_DETERMINISTIC", "BDETR_ROWCHAIN", "BDETR_ZERO_MEMSET")
 
 
 def env_overrides() -> dict:
@@ -296,9 +296,9 @@ def main():
     args = ap.parse_args()
     overrides = env_overrides()               # refuses diagnostic switches; everything else that is set goes into the line
 
-    # Graph replay needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in force when the HIP runtime initialises (boosted_detr_amd/__init__.py).
-    # enable_graph_replay() sets it here - nothing in this process has touched the GPU yet - unless a profiler preload got there
-    # first (then only a value exported before the process started counts: tools/run_profiles_r4.sh exports it).
+    # enable_graph_replay(): the explicit opt-in to DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 - nothing in this process has touched the GPU yet.
+    # Since round 4 the replay does not depend on it (the memset nodes that misbehaved are gone: boosted_detr_amd/__init__.py); it stays
+    # the bench's configuration because it is the one with the 2000-step soak behind it, and the line records whether it is in force.
     import boosted_detr_amd
     graph_ok = boosted_detr_amd.enable_graph_replay()
     import torch
@@ -409,8 +409,8 @@ def main():
                     "check": "the flag is logged to pinned memory by the last kernel of every step and examined 2 steps later (Model._guard_poll)"}
 
     elapsed, guard = timed_region()
-    step_launch = "hipGraph replay (segmented)" if model._graphs else ("eager (graph replay refused: DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 was not in force "
-                                                                        "when HIP initialised - export it)" if graph_refused else "eager")
+    step_launch = "hipGraph replay (segmented)" if model._graphs else ("eager (graph replay refused: BDETR_ZERO_MEMSET=1 without "
+                                                                        "DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in force)" if graph_refused else "eager")
     if model._graphs and (guard["range_redos_in_timed_region"] or guard["overflow_flag_after_run"]):
         # A guard event under graph replay on a synthetic batch that trains cleanly when enqueued eagerly points at the replay, not at
         # the data.  Round 3 re-timed the eager step here; a line measured on a path that just misbehaved is not a
@@ -605,7 +605,9 @@ def main():
             "dtype": dtype_note(model), "arithmetic": arithmetic_note(model), "data": "synthetic",
             "config": {"workload": workload_name(args), "per_gpu_batch": args.batch, "global_batch": global_batch,
                        "parallelism": f"dp{world}", "step_launch": step_launch,
-                       "runtime_switches": {"DEBUG_CLR_GRAPH_PACKET_CAPTURE": os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE")}, "gflop_per_image_algorithmic": gflop_img,
+                       "runtime_switches": {"DEBUG_CLR_GRAPH_PACKET_CAPTURE": os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE"),
+                                            "packet_capture_off_in_force": boosted_detr_amd.packet_capture_off(),
+                                            "zero_fill": "hipMemset nodes" if os.environ.get("BDETR_ZERO_MEMSET") == "1" else "library kernel (no memset nodes in the captured step)"}, "gflop_per_image_algorithmic": gflop_img,
                        "configs3": b32, "configs2": c2, "env_overrides": overrides, "distributed": dist_info},
             "tflops_algorithmic": round(value * gflop_img / 1e3, 2) if gflop_img else None,
             # whole step against the two roofs (the judge's cross-checks): algorithmic FLOPs / step time / 3-product MFMA roof, and the step's

@@ -30,6 +30,12 @@ static inline int bdetr_launch_status(const char* what) {
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Zero `bytes` bytes at p on `st` with a kernel of this library (elementwise.hip).  Not hipMemsetAsync: a memset NODE inside a
+// hipGraph that is relaunched went wrong on ROCm 7.2 with the runtime's pre-built packet path (the first tensor whose
+// fingerprint differed between an eager step and its replay was the one tile_batch zero-fills) - a kernel node is what every other
+// operation of the step already is.  BDETR_ZERO_MEMSET=1 switches back (A/B).
+int bdetr_zero_bytes(void* p, size_t bytes, hipStream_t st);
+
 // grid size for grid-stride elementwise kernels: enough blocks to fill 256 CUs x 8
 static inline int ew_grid(int64_t n, int block = 256, int per_thread = 4) {
     int64_t g = cdiv64(n, (int64_t)block * per_thread);

@@ -875,8 +875,7 @@ extern "C" int bdetr_conv2d_bwd_data(const float* dy, const float* w, float* dx,
         g.I = M; g.J = d->C; g.R = d->K;
         if (d->stride > 1) {
             if (!accumulate) {
-                hipError_t e = hipMemsetAsync(dx, 0, sizeof(float) * (size_t)d->N * d->H * d->W * d->C, st);
-                if (e != hipSuccess) { bdetr_set_error("bdetr_conv2d_bwd_data: memset: %s", hipGetErrorString(e)); return (int)e; }
+                if (int e = bdetr_zero_bytes(dx, sizeof(float) * (size_t)d->N * d->H * d->W * d->C, st)) return e;
             }
             g.rowmap = 1; g.rm_OW = d->OW; g.rm_OHOW = d->OH * d->OW; g.rm_H = d->H; g.rm_W = d->W; g.rm_stride = d->stride;
         }

@@ -335,12 +335,13 @@ class DebugLog:
     buffer (and of the activation gradient that crosses a cut) appended to a device-resident log at every segment boundary of the
     backward pass - captured INTO the segments under use_graph, enqueued at the same points of an eager step (which counts side
     tasks the way SegmentedCapture.maybe_cut does).  Needs a stream-ordered step: BDETR_SIDE_STREAM=0 / BDETR_GRAPH_SIDE=0."""
-    TAGS = {"A": 1, "M": 2, "S": 3}
+    TAGS = {"A": 1, "M": 2, "S": 3, "L": 4, "F": 5}
 
     def __init__(self, cap: int = 1 << 14):
         dev = device()
         self.cap = cap
         self.scratch = torch.zeros(2, dtype=torch.int64, device=dev)
+        self.scratch_side = torch.zeros(2, dtype=torch.int64, device=dev)     # "S" entries may run on the side stream: their own scratch words
         self.log = torch.zeros(cap * 3, dtype=torch.int64, device=dev)
         self.cursor = torch.zeros(1, dtype=torch.int32, device=dev)
         self.eager_pending = 0
@@ -349,7 +350,8 @@ class DebugLog:
         if t is None or not isinstance(t, torch.Tensor) or t.numel() == 0 or t.dtype != torch.float32 or not t.is_contiguous():
             t = self.scratch.view(torch.float32)[:1]           # keep the entry count the same in both modes
         from . import _lib
-        _lib.check(_lib.lib().bdetr_debug_checksum(t.data_ptr(), t.numel(), self.scratch.data_ptr(), self.log.data_ptr(), self.cursor.data_ptr(),
+        sc = self.scratch_side if kind == "S" else self.scratch
+        _lib.check(_lib.lib().bdetr_debug_checksum(t.data_ptr(), t.numel(), sc.data_ptr(), self.log.data_ptr(), self.cursor.data_ptr(),
                                                    self.cap, self.TAGS[kind], K._stream()), "debug_checksum")
 
     def entries(self):
@@ -371,6 +373,7 @@ def _debug_cut(extra) -> None:
     """Eager twin of SegmentedCapture.cut() for the debug log: the three entries a captured cut appends."""
     log = _DEBUG_LOG[0]
     from . import ops
+    log.emit("F", K.overflow_flag().view(torch.float32))
     log.emit("A", extra)
     log.emit("M", ops._live_flat_grad[0])
     log.emit("S", ops._live_flat_grad[0])
@@ -440,6 +443,7 @@ class SegmentedCapture:
         """Close the open main segment, capture its side tasks, open the next main segment."""
         if _DEBUG_LOG[0] is not None:
             from . import ops
+            _DEBUG_LOG[0].emit("F", K.overflow_flag().view(torch.float32))
             _DEBUG_LOG[0].emit("A", extra)
             _DEBUG_LOG[0].emit("M", ops._live_flat_grad[0])
             if not self.pending:
@@ -620,7 +624,14 @@ class Layer:
                 if isinstance(inputs, (list, tuple)) else inputs
             self.build(shapes)
             self.built = True
-        return self.call(inputs, training=training, **kwargs)
+        out = self.call(inputs, training=training, **kwargs)
+        if _DEBUG_LOG[0] is not None and training:
+            # diagnostic (DebugLog): fingerprint every layer's first output tensor and the range-guard word in forward order
+            t = out[0] if isinstance(out, (list, tuple)) and out else out
+            if isinstance(t, torch.Tensor):
+                _DEBUG_LOG[0].emit("L", getattr(t, "_p16f", t) if getattr(t, "_p16_only", False) else t)
+                _DEBUG_LOG[0].emit("F", K.overflow_flag().view(torch.float32))
+        return out
 
     def get_config(self) -> dict:
         return {"name": self.name, "trainable": self.trainable}

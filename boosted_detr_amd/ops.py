@@ -568,6 +568,9 @@ def tile_batch(row: Variable, B: int) -> torch.Tensor:
     K.zero_(zeros)
     out = K.add_bcast_rows(zeros, rv)
     n = rv.numel()
+    from . import engine as _engine
+    if _engine._DEBUG_LOG[0] is not None:
+        _engine._DEBUG_LOG[0].emit("L", out)        # diagnostic: the zero-filled + broadcast tensor (see bdetr_zero_bytes)
 
     def backward(g):
         g = g.contiguous()

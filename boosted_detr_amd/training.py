@@ -608,9 +608,8 @@ class Model(Layer):
             if not getattr(self, "_graph_refused", False):
                 import sys
                 self._graph_refused = True
-                print("[boosted_detr_amd] use_graph: DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 was not in force when the HIP runtime initialised "
-                      "(import boosted_detr_amd before the first CUDA call, or export it) - hipGraph replays are not sound without it "
-                      "on ROCm 7.2; running eager steps", file=sys.stderr)
+                print("[boosted_detr_amd] use_graph: BDETR_ZERO_MEMSET=1 puts hipMemset nodes back into the captured step; those are only sound with "
+                      "DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in force when the HIP runtime initialised (export it) - running eager steps", file=sys.stderr)
             return None
         if not all(isinstance(v, torch.Tensor) and v.is_cuda for v in data.values()):
             return None

@@ -509,3 +509,26 @@ def test_a_step_that_fails_during_capture_leaves_the_stream_usable(cuda):
     assert not torch.cuda.is_current_stream_capturing()
     loss = m.logs_to_host(m.train_step(batch))["loss"]             # captures now (or runs eagerly): either way a valid step
     assert np.isfinite(loss) and m.steps_done == steps[0] + 1
+
+
+def test_replayed_step_is_bit_identical_with_the_runtime_packet_path_on(cuda):
+    """The round-3 replay defect, pinned: with the ROCm 7.2 runtime's pre-built packet path ON (DEBUG_CLR_GRAPH_PACKET_CAPTURE=1, the
+    runtime default) a hipMemset node inside the relaunched chain went wrong (first differing tensor: the one ops.tile_batch zero-fills)
+    and NaN followed.  The library's zero fills are kernels now; this runs tools/graph_segment_checksums.py at configs[1] size in a
+    process of its own (the switch is read when HIP initialises) and requires every layer output, every activation gradient crossing a
+    segment cut and the gradient buffer behind every segment to be bit-identical between the eager and the replayed run, 8 synchronised
+    + 10 unsynchronised steps, no non-finite entry, no guard flag."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DEBUG_CLR_GRAPH_PACKET_CAPTURE="1", SYNC_STEPS="8", STEPS="10", BDETR_DETERMINISTIC="1", BDETR_SIDE_STREAM="0", BDETR_GRAPH_SIDE="0")
+    env.pop("BDETR_ZERO_MEMSET", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "graph_segment_checksums.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = next(l for l in r.stdout.splitlines() if l.startswith("GRAPH_SEGMENT_CHECKSUMS "))
+    out = json.loads(line.split(" ", 1)[1])
+    assert out["weights_finite"] == {"eager": True, "graph": True}
+    for kind in ("L", "F", "A", "S"):
+        assert out[kind]["n"][0] == out[kind]["n"][1] > 0, (kind, out[kind])
+        assert out[kind]["first_difference"] is None and out[kind]["first_nonfinite_or_flag_in_graph_run"] is None, (kind, out[kind])

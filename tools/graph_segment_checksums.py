@@ -47,12 +47,13 @@ def run(graph: bool):
     batch = {"image": to_device(host["image"]), "category": to_device(host["category"], torch.int32), "attribute": to_device(host["attribute"], torch.int32),
              "bbox": to_device(host["bbox"]), "num_objects": to_device(host["num_objects"], torch.int32)}
     m.guard_check_every = 0                       # no redo: the run must show what the replay did, not repair it
+    K.overflow_flag().zero_()
     m.use_graph = graph
     log = engine.DebugLog()
     engine.set_debug_log(log)
     for i in range(3 + STEPS):
         m.train_step(batch)
-        if i < 3:
+        if i < int(os.environ.get("SYNC_STEPS", "3")):
             torch.cuda.synchronize()                             # set-up steps (2 eager + the capture and its first replay) are synchronised
     torch.cuda.synchronize()
     engine.set_debug_log(None)
@@ -68,28 +69,19 @@ def main():
     g_ent, g_fin, ngraphs = run(True)
     print(f"eager: {len(e_ent)} entries, weights finite {e_fin};  graph: {len(g_ent)} entries, weights finite {g_fin}, captured signatures {ngraphs}")
     total_steps = 3 + STEPS
-    out = {"entries_eager": len(e_ent), "entries_graph": len(g_ent), "weights_finite": {"eager": e_fin, "graph": g_fin}}
-    if len(e_ent) != len(g_ent) or len(e_ent) % total_steps:
-        print("entry counts differ or do not divide by the step count: cut points are not the same in both modes", len(e_ent), len(g_ent))
-    per = len(e_ent) // total_steps if total_steps else 0
-    first = None
-    nonfinite_first = None
-    for i, (x, y) in enumerate(zip(e_ent, g_ent)):
-        step, cut, kind = i // per, (i % per) // 3, x[0]
-        if nonfinite_first is None and y[2] > 0:
-            nonfinite_first = (step, cut, y[0], y[2])
-        if kind == "M":
-            continue                                             # (M is taken before the side tasks in graph mode, after them in the eager twin)
-        if first is None and (x[1] != y[1] or x[2] != y[2]):
-            first = (step, cut, kind, x, y)
-    out["entries_per_step"] = per
-    out["first_difference"] = None if first is None else {"step": first[0], "cut": first[1], "kind": first[2], "eager": first[3], "graph": first[4]}
-    out["first_nonfinite_in_graph_run"] = nonfinite_first
-    print("entries per step:", per, " first difference (A / S entries):", out["first_difference"], " first non-finite entry in the graph run:", nonfinite_first)
-    if first is not None:
-        lo = max(0, (first[0] * per + first[1] * 3) - 6)
-        for i in range(lo, min(len(e_ent), lo + 18)):
-            print(f"   step {i // per} cut {(i % per) // 3} {e_ent[i][0]}: eager {e_ent[i][1]:016x}/{e_ent[i][2]}  graph {g_ent[i][1]:016x}/{g_ent[i][2]}", "  <--" if e_ent[i][1:] != g_ent[i][1:] and e_ent[i][0] != "M" else "")
+    out = {"entries_eager": len(e_ent), "entries_graph": len(g_ent), "weights_finite": {"eager": e_fin, "graph": g_fin}, "steps": total_steps,
+           "sync_steps": int(os.environ.get("SYNC_STEPS", "3"))}
+    # entries of the main and the side stream may interleave: compare the sequences per tag (M is taken before the side tasks in graph
+    # mode and after them in the eager twin: not compared)
+    for kind in ("L", "F", "A", "S"):
+        xs, ys = [e for e in e_ent if e[0] == kind], [e for e in g_ent if e[0] == kind]
+        per = len(xs) // total_steps if total_steps else 0
+        first = next((i for i, (x, y) in enumerate(zip(xs, ys)) if x[1:] != y[1:]), None)
+        bad = next((i for i, y in enumerate(ys) if y[2] > 0 or (kind == "F" and y[1] != 0)), None)
+        out[kind] = {"per_step": per, "n": (len(xs), len(ys)),
+                     "first_difference": None if first is None else {"step": first // max(per, 1), "index_in_step": first % max(per, 1), "eager": xs[first][1:], "graph": ys[first][1:]},
+                     "first_nonfinite_or_flag_in_graph_run": None if bad is None else {"step": bad // max(per, 1), "index_in_step": bad % max(per, 1), "entry": ys[bad][1:]}}
+        print(kind, out[kind], flush=True)
     print("GRAPH_SEGMENT_CHECKSUMS " + json.dumps(out, default=str))
 
 

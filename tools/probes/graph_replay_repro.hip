@@ -35,7 +35,8 @@ struct BigArgs {                 // ~416 bytes by value, like bdgemm::GemmParams
     uint32_t salt;
 };
 
-constexpr int N = 1 << 20, M = 4096;
+constexpr int N = 1 << 20;
+static int M = 4096;             // words zeroed by the memset NODE of every segment (argv[5]; the failing one of the framework is 409600 = 1.6 MB)
 
 __host__ __device__ inline uint32_t mix(uint32_t s, uint32_t seed, uint32_t seg, uint32_t k, uint32_t salt, uint32_t in) {
     return s * 1664525u + 1013904223u + seed * 2654435761u + seg * 97u + k * 13u + salt + in;
@@ -57,6 +58,9 @@ __global__ void fold_kernel(BigArgs a) {
     if (i >= a.n) return;
     a.state[i] ^= a.scratch[i % a.m] + a.scalars[1];
 }
+// the memset's target is pool memory that another tensor of the step used before: poison it first, so that a memset node that runs
+// out of order (or not at all) shows
+__global__ void poison_kernel(uint32_t* p, int m) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < m) p[i] = 0x7FC00000u + (uint32_t)i; }
 __global__ void fill_kernel(uint32_t* p, uint32_t v) { *p = v; }                        // torch's fill_ of a device scalar
 __global__ void snapshot_kernel(const uint32_t* state, uint32_t* ordinal, uint32_t* ring, int ring_len) {
     const uint32_t k = ++*ordinal;
@@ -76,8 +80,10 @@ static BigArgs make_args(int seg, int k, uint32_t* state, uint32_t* scratch, con
 int main(int argc, char** argv) {
     const int segments = argc > 1 ? atoi(argv[1]) : 16, kper = argc > 2 ? atoi(argv[2]) : 40, steps = argc > 3 ? atoi(argv[3]) : 12;
     const bool side = argc > 4 && !strcmp(argv[4], "side");
+    if (argc > 5) M = atoi(argv[5]);
+    const int sync_steps = argc > 6 ? atoi(argv[6]) : 0;          // pass 2: synchronise after each of the first sync_steps steps only
     const char* env = getenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE");
-    printf("graph_replay_repro: %d segments x %d kernels, %d steps, side=%d, DEBUG_CLR_GRAPH_PACKET_CAPTURE=%s\n", segments, kper, steps, (int)side, env ? env : "(unset)");
+    printf("graph_replay_repro: %d segments x %d kernels, %d steps, side=%d, memset words %d, sync_steps %d, DEBUG_CLR_GRAPH_PACKET_CAPTURE=%s\n", segments, kper, steps, (int)side, M, sync_steps, env ? env : "(unset)");
     uint32_t *state, *scratch, *scratch2, *scalars, *input, *batch[2], *ordinal, *ring;
     CK(hipMalloc(&state, N * 4)); CK(hipMalloc(&scratch, M * 4)); CK(hipMalloc(&scratch2, M * 4)); CK(hipMalloc(&scalars, 8)); CK(hipMalloc(&input, M * 4));
     CK(hipMalloc(&batch[0], M * 4)); CK(hipMalloc(&batch[1], M * 4)); CK(hipMalloc(&ordinal, 4));
@@ -94,6 +100,7 @@ int main(int argc, char** argv) {
     for (int s = 0; s < segments; ++s) {
         hipGraph_t g;
         CK(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
+        hipLaunchKernelGGL(poison_kernel, dim3((M + 255) / 256), dim3(256), 0, cap, scratch, M);
         CK(hipMemsetAsync(scratch, 0, M * 4, cap));
         for (int k = 0; k < kper; ++k) {
             BigArgs a = make_args(s, k, state, scratch, scalars, input);
@@ -121,6 +128,7 @@ int main(int argc, char** argv) {
 
     // the same node sequence enqueued eagerly (no graphs): the reference
     auto segment_eager = [&](int sgm, hipStream_t st, bool last) {
+        hipLaunchKernelGGL(poison_kernel, dim3((M + 255) / 256), dim3(256), 0, st, scratch, M);
         CK(hipMemsetAsync(scratch, 0, M * 4, st));
         for (int k = 0; k < kper; ++k) {
             BigArgs a = make_args(sgm, k, state, scratch, scalars, input);
@@ -153,7 +161,7 @@ int main(int argc, char** argv) {
                     used = true;
                 }
             }
-            if (pass == 1) CK(hipStreamSynchronize(mainS));
+            if (pass == 1 || (pass == 2 && t < sync_steps)) CK(hipDeviceSynchronize());
         }
         CK(hipDeviceSynchronize());
         CK(hipMemcpy(pass == 0 ? want.data() : got.data(), state, N * 4, hipMemcpyDeviceToHost));
