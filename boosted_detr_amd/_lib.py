@@ -42,6 +42,21 @@ class BnBwdFuse(C.Structure):
                 ("part_g", C.c_void_p), ("part_gx", C.c_void_p), ("relu_mask", C.c_void_p)]
 
 
+class RowchainFwdDesc(C.Structure):
+    _fields_ = ([("M", C.c_int64), ("nstages", C.c_int), ("eps", C.c_float), ("rate", C.c_float), ("ctx", C.c_void_p), ("resid", C.c_void_p),
+                 ("w", C.c_void_p * 3), ("bias", C.c_void_p * 3)]
+                + [(n, C.c_void_p) for n in ("g1", "b1", "g2", "b2", "pre1", "x1", "mean1", "rstd1", "h", "pre2", "x2", "mean2", "rstd2")]
+                + [("seed1", C.c_uint64), ("seed2", C.c_uint64), ("seed_base", C.c_void_p)])
+
+
+class RowchainBwdDesc(C.Structure):
+    _fields_ = ([("M", C.c_int64), ("nstages", C.c_int), ("rate", C.c_float)]
+                + [(n, C.c_void_p) for n in ("dout", "pre2", "mean2", "rstd2", "g2", "h", "pre1", "mean1", "rstd1", "g1")]
+                + [("wt", C.c_void_p * 3)]
+                + [(n, C.c_void_p) for n in ("G2", "G1", "G0", "dresid", "dctx", "partials")]
+                + [("seed1", C.c_uint64), ("seed2", C.c_uint64), ("seed_base", C.c_void_p)])
+
+
 class LossDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("M", C.c_int), ("N", C.c_int), ("C", C.c_int), ("A", C.c_int),
                 ("category_weight", C.c_float), ("attribute_weight", C.c_float),
@@ -125,6 +140,13 @@ SIGNATURES = {
     "bdetr_add_dropout_layernorm_fwd": (I, [P, P, P, P, P, P, P, L, I, F, F, U64, P, P]),
     "bdetr_ln_bwd_chunks": (I, [L]),
     "bdetr_add_dropout_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, P, L, I, F, U64, P, I, P]),
+    "bdetr_rowchain_fwd": (I, [C.POINTER(RowchainFwdDesc), P]),
+    "bdetr_rowchain_bwd": (I, [C.POINTER(RowchainBwdDesc), P]),
+    "bdetr_rowchain_reduce": (I, [P, I, C.POINTER(C.c_void_p * 7), C.POINTER(C.c_int * 7), P]),
+    "bdetr_rowchain_width": (I, []),
+    "bdetr_rowchain_pack_elems": (L, []),
+    "bdetr_rowchain_partial_rows": (I, [L]),
+    "bdetr_rowchain_pack_weights": (I, [P, I, P, P]),
     "bdetr_resize_bilinear_nhwc": (I, [P, I, I, I, I, P, I, I, P]),
     "bdetr_layernorm_act_fwd": (I, [P, L, I, I, P, P, F, F, P, I, P]),
     "bdetr_copy_cols": (I, [P, L, I, I, P, I, I, P]),

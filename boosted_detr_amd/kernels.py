@@ -13,7 +13,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import BnAffine, BnBwdFuse, ConvDesc, GemmDesc, LossDesc, check
+from ._lib import BnAffine, BnBwdFuse, ConvDesc, GemmDesc, LossDesc, RowchainBwdDesc, RowchainFwdDesc, check
 
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 
@@ -723,6 +723,76 @@ def add_dropout_layernorm_bwd(dout, x2d, y2d, gamma, mean, rstd, rate=0.0, seed=
     check(L.bdetr_add_dropout_layernorm_bwd(_p(dout), _p(x2d), _p(y2d), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dy), _p(dgamma), _p(dbeta),
                                             _p(ws), rows, D, rate, seed, _p(seed_base), 0, _stream()), "add_dropout_layernorm_bwd")
     return dx, dy, dgamma, dbeta
+
+
+# --------------------------------------------------------------------------------------
+# row chain (csrc/rowchain.hip): out-projection + LayerNorm (+ FFN + LayerNorm) of a transformer layer in one launch
+# --------------------------------------------------------------------------------------
+ROWCHAIN_WIDTH = 256
+
+
+def rowchain_pack_weights(table: torch.Tensor) -> None:
+    """table: int64 [n,3] device tensor of {W [256,256] fp32, forward copy | 0, backward copy | 0} rows."""
+    _chk(table, dtype=torch.int64)
+    check(_lib.lib().bdetr_rowchain_pack_weights(_p(table), table.shape[0], _p(overflow_flag()), _stream()), "rowchain_pack_weights")
+
+
+def rowchain_fwd(ctx2d, resid2d, packs, biases, ln1, ln2, eps, rate, seed1, seed2, seed_base):
+    """packs / biases: 1 or 3 packed forward copies / bias vectors (Wo[, W1, W2]); ln1 / ln2: (gamma, beta) value tensors (ln2 None for
+    one stage).  Returns a dict of the outputs and saved tensors."""
+    n = len(packs)
+    _chk(ctx2d, resid2d, *biases, *ln1, *(ln2 or ()))
+    M, D = ctx2d.shape
+    assert D == ROWCHAIN_WIDTH and n in (1, 3) and resid2d.shape == ctx2d.shape
+    e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=ctx2d.device)
+    o = {"pre1": e(M, D), "x1": e(M, D), "mean1": e(M), "rstd1": e(M)}
+    if n == 3:
+        o.update({"h": e(M, D), "pre2": e(M, D), "x2": e(M, D), "mean2": e(M), "rstd2": e(M)})
+    d = RowchainFwdDesc()
+    d.M, d.nstages, d.eps, d.rate = M, n, float(eps), float(rate)
+    d.ctx, d.resid = _p(ctx2d), _p(resid2d)
+    for k in range(n):
+        d.w[k], d.bias[k] = _p(packs[k]), _p(biases[k])
+    d.g1, d.b1 = _p(ln1[0]), _p(ln1[1])
+    if n == 3:
+        d.g2, d.b2 = _p(ln2[0]), _p(ln2[1])
+    for k, v in o.items():
+        setattr(d, k, _p(v))
+    d.seed1, d.seed2, d.seed_base = int(seed1), int(seed2), _p(seed_base)
+    check(_lib.lib().bdetr_rowchain_fwd(C.byref(d), _stream()), "rowchain_fwd")
+    return o
+
+
+def rowchain_bwd(dout2d, saved, packs_t, gammas, rate, seed1, seed2, seed_base):
+    """saved: rowchain_fwd's dict; packs_t: the packed backward copies; gammas: (gamma1[, gamma2]).  Returns (dctx, dresid, [G0, G1, G2],
+    partials, nparts)."""
+    n = len(packs_t)
+    _chk(dout2d)
+    M, D = dout2d.shape
+    e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dout2d.device)
+    L = _lib.lib()
+    nparts = L.bdetr_rowchain_partial_rows(M)
+    G = [e(M, D) for _ in range(n)]
+    dctx, dresid, partials = e(M, D), e(M, D), e(nparts, 7, D)
+    d = RowchainBwdDesc()
+    d.M, d.nstages, d.rate, d.dout = M, n, float(rate), _p(dout2d)
+    d.pre1, d.mean1, d.rstd1, d.g1 = _p(saved["pre1"]), _p(saved["mean1"]), _p(saved["rstd1"]), _p(gammas[0])
+    if n == 3:
+        d.pre2, d.mean2, d.rstd2, d.g2, d.h = _p(saved["pre2"]), _p(saved["mean2"]), _p(saved["rstd2"]), _p(gammas[1]), _p(saved["h"])
+        d.G1, d.G2 = _p(G[1]), _p(G[2])
+    for k in range(n):
+        d.wt[k] = _p(packs_t[k])
+    d.G0, d.dresid, d.dctx, d.partials = _p(G[0]), _p(dresid), _p(dctx), _p(partials)
+    d.seed1, d.seed2, d.seed_base = int(seed1), int(seed2), _p(seed_base)
+    check(L.bdetr_rowchain_bwd(C.byref(d), _stream()), "rowchain_bwd")
+    return dctx, dresid, G, partials, nparts
+
+
+def rowchain_reduce(partials, nparts, dsts, accumulate):
+    """dsts: 7 tensors or None ({dgamma2, dbeta2, dbias2, dbias1, dgamma1, dbeta1, dbias0}); accumulate: 7 flags."""
+    ptrs = (C.c_void_p * 7)(*[_p(t) for t in dsts])
+    acc = (C.c_int * 7)(*[int(bool(a)) for a in accumulate])
+    check(_lib.lib().bdetr_rowchain_reduce(_p(partials), nparts, C.byref(ptrs), C.byref(acc), _stream()), "rowchain_reduce")
 
 
 def _unary(name, x, out=None):

@@ -666,6 +666,95 @@ def add_dropout_layernorm(x: torch.Tensor, y: torch.Tensor, gamma: Variable, bet
 
 
 # ----------------------------------------------------------------------------------------
+# row chain: OutputProjection + Add/Dropout/LayerNorm (+ FeedForwardBlock) of a transformer layer as one launch per direction
+# ----------------------------------------------------------------------------------------
+ROWCHAIN = [os.environ.get("BDETR_ROWCHAIN", "1") != "0"]
+
+
+def rowchain_active(width: int) -> bool:
+    """The fused path exists for model width 256 under the 'split' policy (csrc/rowchain.hip: f16-pair forward, bf16-pair gradient
+    products); every other case runs the separate GEMM / LayerNorm launches."""
+    return ROWCHAIN[0] and width == K.ROWCHAIN_WIDTH and K.get_gemm_precision() == "split"
+
+
+class _RowchainPacks:
+    """Forward (f16 pairs of 2^8 W, MFMA fragment order) and backward (bf16 pairs of W^T) copies of every Dense kernel on a row
+    chain, in persistent buffers, refreshed by ONE multi-matrix launch the first time a copy is asked for after the weights changed
+    (the same scheme as _PackedWeights for the conv kernels)."""
+
+    def __init__(self):
+        self.rows, self.table, self.version = [], None, -1
+
+    def get(self, w: Variable):
+        import weakref
+        c = getattr(w, "_rc", None)
+        if c is None or c[0].data_ptr() != w.value.data_ptr():
+            from . import _lib
+            n = int(_lib.lib().bdetr_rowchain_pack_elems())
+            dev = w.value.device
+            c = (w.value, torch.empty(n, dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.float32, device=dev))
+            w._rc = c
+            self.rows = [r for r in self.rows if r[0]() is not None and r[0]() is not w]
+            self.rows.append((weakref.ref(w),) + c)
+            self.table, self.version = None, -1
+        if self.version != WEIGHTS_VERSION[0]:
+            if self.table is None:
+                import numpy as np
+                rows = np.array([[v.data_ptr(), f.data_ptr(), b.data_ptr()] for _, v, f, b in self.rows], np.int64)
+                self.table = torch.from_numpy(rows).to(w.value.device)
+            K.rowchain_pack_weights(self.table)
+            self.version = WEIGHTS_VERSION[0]
+        return c[1], c[2]
+
+
+_RC_PACKED = _RowchainPacks()
+
+
+def attention_out_chain(ctx: torch.Tensor, resid: torch.Tensor, out_proj, ln1, ffn, eps: float, rate: float, training: bool) -> torch.Tensor:
+    """LN1(resid + Dropout(ctx Wo^T + bo)) and, with ``ffn`` = (W1, b1, W2, b2, gamma2, beta2), the FeedForwardBlock behind it
+    (transformers.py:101,135-137,174-180) as ONE forward launch; the backward closure runs one launch for every data gradient, LayerNorm
+    gradient and bias gradient of the chain, one for their partial sums, and the three weight gradients as side tasks.
+    out_proj = (Wo, bo), ln1 = (gamma1, beta1): Variables.  ctx, resid: [B, T, 256]."""
+    r = rate if training else 0.0
+    seed1 = _next_dropout_seed() if r > 0.0 else 0                  # the same site order as the unfused path: identical masks
+    seed2 = _next_dropout_seed() if (r > 0.0 and ffn is not None) else 0
+    base = dropout_seed_tensor() if r > 0.0 else None
+    ctx2d, res2d = _2d(ctx.contiguous()), _2d(resid.contiguous())
+    Wo, bo = out_proj
+    g1, b1 = ln1
+    ws = [Wo] + ([ffn[0], ffn[2]] if ffn is not None else [])
+    bs = [bo] + ([ffn[1], ffn[3]] if ffn is not None else [])
+    packs = [_RC_PACKED.get(w) for w in ws]
+    saved = K.rowchain_fwd(ctx2d, res2d, [p[0] for p in packs], [b.value for b in bs], (g1.value, b1.value),
+                           (ffn[4].value, ffn[5].value) if ffn is not None else None, eps, r, seed1, seed2, base)
+    out = (saved["x2"] if ffn is not None else saved["x1"]).view(resid.shape)
+
+    def backward(g_out):
+        gammas = (g1.value,) + ((ffn[4].value,) if ffn is not None else ())
+        packs_t = [_RC_PACKED.get(w)[1] for w in ws]
+        dctx, dres, G, partials, nparts = K.rowchain_bwd(_2d(g_out.contiguous()), saved, packs_t, gammas, r, seed1, seed2, base)
+        xs = [ctx2d] + ([saved["x1"], saved["h"]] if ffn is not None else [])
+        vec_vars = ([ffn[4], ffn[5], ffn[3], ffn[1]] if ffn is not None else [None] * 4) + [g1, b1, bo]
+
+        def param_grads():
+            sinks = [GradSink(v) if v is not None else None for v in vec_vars]
+            K.rowchain_reduce(partials, nparts, [s_.buf if s_ is not None else None for s_ in sinks], [0] * 7)
+            for s_ in sinks:
+                if s_ is not None:
+                    s_.commit()
+            for w, g, x in zip(ws, G, xs):
+                if w.needs_grad:
+                    s_ = GradSink(w)
+                    K.linear_bwd_weight(g, x, dw=s_.buf, prezeroed=s_.mode == "direct")
+                    s_.commit()
+        side_task(param_grads, partials, *G, *xs)
+        return _own(dctx.view(ctx.shape)), _own(dres.view(resid.shape))
+
+    _rec([out], [ctx, resid], backward)
+    return out
+
+
+# ----------------------------------------------------------------------------------------
 # head activations
 # ----------------------------------------------------------------------------------------
 def softmax_lastdim(x: torch.Tensor) -> torch.Tensor:

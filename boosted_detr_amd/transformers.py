@@ -62,14 +62,18 @@ class MultiheadAttention(Layer):
     def call(self, inputs, attention_mask=None, training=False):
         if attention_mask is not None:
             raise NotImplementedError("the hot path always calls MultiheadAttention with attention_mask=None")
+        return self.OutputProjection(self.context(inputs))
+
+    def context(self, inputs):
+        """Everything of the layer up to (not including) OutputProjection: the three projections, the attention core and the
+        reference's reshape without a head permute.  [B, q, h*d]."""
         query, key, value = inputs
         q, k, v = ops.dense_group([query, key, value],
                                   [self.QueryProjection.kernel, self.KeyProjection.kernel, self.ValueProjection.kernel],
                                   [self.QueryProjection.bias, self.KeyProjection.bias, self.ValueProjection.bias])
         o = ops.attention_core(q, k, v, self.num_attention_heads)          # [B,h,q,d]
         B, h, nq, d = o.shape
-        o = ops.reshape(o, (B, nq, h * d))                                  # ReshapePreOutput: no permute (line 100)
-        return self.OutputProjection(o)
+        return ops.reshape(o, (B, nq, h * d))                               # ReshapePreOutput: no permute (line 100)
 
 
 class AttentionBlock(Layer):
@@ -115,6 +119,33 @@ class FeedForwardBlock(Layer):
         return ops.add_dropout_layernorm(features, y, self.ln_gamma, self.ln_beta, LN_EPS, self.dropout_rate, training)
 
 
+def attention_then(attn: AttentionBlock, ffn, inputs, training: bool):
+    """AttentionBlock(inputs) followed by ``ffn`` (a FeedForwardBlock or None), exactly as the reference composes them
+    (transformers.py:228-231, 348-351, 381-392) - on the fused row-chain kernels when they apply (csrc/rowchain.hip: a training step
+    under the 'split' policy at model width 256, equal dropout rates, layers already built), otherwise layer by layer."""
+    query, key, value = inputs
+    fused = training and ops.rowchain_active(query.shape[-1]) and (ffn is None or ffn.dropout_rate == attn.dropout_rate)
+    if fused:
+        # build-by-first-call, as Layer.__call__ would do it: the very first step takes the same path as every later one
+        shapes = [tuple(t.shape) for t in (query, key, value)]
+        for layer, shp in ((attn, shapes), (getattr(attn, "AttentionLayer", None), shapes), (ffn, [shapes[0]])):
+            if layer is not None and not layer.built:
+                layer.build(shp)
+                layer.built = True
+        if not attn.AttentionLayer.built:                     # (created by attn.build just now)
+            attn.AttentionLayer.build(shapes)
+            attn.AttentionLayer.built = True
+        fused = attn.AttentionLayer.num_attention_heads * attn.AttentionLayer.dim == query.shape[-1]
+    if not fused:
+        x = attn([query, key, value], training=training)
+        return ffn([x], training=training) if ffn is not None else x
+    mha = attn.AttentionLayer
+    ctx = mha.context([query, key, value])
+    ff = None if ffn is None else (ffn.DenseRelu.kernel, ffn.DenseRelu.bias, ffn.DenseLinear.kernel, ffn.DenseLinear.bias, ffn.ln_gamma, ffn.ln_beta)
+    return ops.attention_out_chain(ctx, query, (mha.OutputProjection.kernel, mha.OutputProjection.bias), (attn.ln_gamma, attn.ln_beta), ff,
+                                   LN_EPS, attn.dropout_rate, training)
+
+
 class EncoderBlock(Layer):
     def __init__(self, num_attention_heads, **kwargs):
         super().__init__(**kwargs)
@@ -134,8 +165,7 @@ class EncoderBlock(Layer):
     def call(self, inputs, training=False):
         encoder_features, encoder_positional = inputs           # positional is [T,D] (batch-broadcast)
         qk = ops.add_bcast(encoder_features, encoder_positional)  # Add1 and Add2 compute the same tensor (224-225)
-        x = self.SelfAttentionBlock([qk, qk, encoder_features], training=training)
-        return self.FeedForwardBlock([x], training=training)
+        return attention_then(self.SelfAttentionBlock, self.FeedForwardBlock, [qk, qk, encoder_features], training)
 
 
 def positional_init(r: int, c: int, D: int) -> np.ndarray:
@@ -195,8 +225,7 @@ class DecoderBlock_NoSelfAttention(Layer):
 
     def call(self, inputs, training=False):
         encoder_value, decoder_features, encoder_key, decoder_positional = inputs
-        x = self.JointAttentionBlock([decoder_features, encoder_key, encoder_value], training=training)
-        return self.FeedForwardBlock([x], training=training)
+        return attention_then(self.JointAttentionBlock, self.FeedForwardBlock, [decoder_features, encoder_key, encoder_value], training)
 
 
 class DecoderBlock(Layer):
@@ -215,9 +244,8 @@ class DecoderBlock(Layer):
 
     def call(self, inputs, training=False):
         encoder_value, decoder_features, encoder_key, decoder_positional = inputs
-        x = self.SelfAttentionBlock([decoder_features, decoder_features, decoder_features], training=training)  # no positional (378-380)
-        x = self.JointAttentionBlock([x, encoder_key, encoder_value], training=training)
-        return self.FeedForwardBlock([x], training=training)
+        x = attention_then(self.SelfAttentionBlock, None, [decoder_features, decoder_features, decoder_features], training)  # no positional (378-380)
+        return attention_then(self.JointAttentionBlock, self.FeedForwardBlock, [x, encoder_key, encoder_value], training)
 
 
 class DecoderPrep(Layer):

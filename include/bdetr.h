@@ -378,6 +378,57 @@ int bdetr_add_dropout_layernorm_bwd(const float* dout, const float* x, const flo
                                     float* dgamma, float* dbeta, float* ws, int64_t rows, int D,
                                     float rate, uint64_t seed, const uint64_t* seed_base, int accumulate_dx, void* stream);
 
+/* ----------------------------------------------------------------------
+ * Row chain (csrc/rowchain.hip, ABI 6): the row-local part of a transformer layer between two attention cores as ONE launch
+ * per direction, model width 256 (bdetr_rowchain_width).  Replaces, for an AttentionBlock followed by a FeedForwardBlock
+ * (transformers.py:101 OutputProjection, 135-137 Add + Dropout + LayerNormalization, 174-177 DenseRelu / DenseLinear, 178-180
+ * Add + Dropout + LayerNormalization) the five forward and ~twenty backward launches of the unfused path:
+ *     a = ctx Wo^T + bo;  x1 = LN1(resid + drop1(a));  h = relu(x1 W1^T + b1);  f = h W2^T + b2;  x2 = LN2(x1 + drop2(f))
+ * nstages = 3: the whole chain; nstages = 1: stage 1 only (an AttentionBlock followed by another AttentionBlock:
+ * DecoderBlock's self-attention, transformers.py:378-383).  All activations fp32 [M][256] row-major; weights PRE-PACKED by
+ * bdetr_rowchain_pack_weights (per-optimizer-step, one launch for all matrices): forward copy = f16 pairs of 2^8 W in MFMA
+ * fragment order, backward copy = bf16 pairs of W^T (the 'split' policy's arithmetic: BDETR_GEMM_SPLIT above; other policies
+ * use the unfused path).  Dropout: the hash, seeds and element indices of bdetr_add_dropout_layernorm_* - same masks.
+ * Forward saves what the backward needs: pre1 / pre2 (the LayerNorm inputs resid + drop(a), x1 + drop(f)), mean / rstd, h.
+ * ---------------------------------------------------------------------- */
+typedef struct {
+    int64_t M; int nstages; float eps, rate;
+    const float* ctx; const float* resid;
+    const void* w[3];            /* packed forward copies of Wo, W1, W2 */
+    const float* bias[3];
+    const float* g1; const float* b1; const float* g2; const float* b2;      /* LayerNorm gamma / beta */
+    float* pre1; float* x1; float* mean1; float* rstd1;                      /* x1 = the result when nstages == 1 */
+    float* h; float* pre2; float* x2; float* mean2; float* rstd2;
+    uint64_t seed1, seed2; const uint64_t* seed_base;
+} bdetr_rowchain_fwd_desc;
+int bdetr_rowchain_fwd(const bdetr_rowchain_fwd_desc* d, void* stream);
+/* Backward of the same chain from dout = gradient of x2 (nstages 3) or x1 (nstages 1): writes dctx and dresid, the three Dense
+ * layers' output gradients G0 (of a), G1 (of the ReLU's input), G2 (of f) - the operands of their weight gradients, which stay
+ * GEMMs of their own (dW = G^T X: bdetr_gemm) - and one row of partial sums per 32-token workgroup for the seven vector
+ * gradients {dgamma2, dbeta2, dbias2, dbias1, dgamma1, dbeta1, dbias0} (for nstages == 1 only the last three are written):
+ * partials holds bdetr_rowchain_partial_rows(M) x 7 x 256 floats; bdetr_rowchain_reduce folds them in a fixed order into up to
+ * seven destinations (dst7[v] may be null; accumulate7[v] != 0: add to what is there). */
+typedef struct {
+    int64_t M; int nstages; float rate;
+    const float* dout;
+    const float* pre2; const float* mean2; const float* rstd2; const float* g2;
+    const float* h;
+    const float* pre1; const float* mean1; const float* rstd1; const float* g1;
+    const void* wt[3];           /* packed backward copies of Wo, W1, W2 */
+    float* G2; float* G1; float* G0;
+    float* dresid; float* dctx;
+    float* partials;
+    uint64_t seed1, seed2; const uint64_t* seed_base;
+} bdetr_rowchain_bwd_desc;
+int bdetr_rowchain_bwd(const bdetr_rowchain_bwd_desc* d, void* stream);
+int bdetr_rowchain_reduce(const float* partials, int nparts, float* const* dst7, const int* accumulate7, void* stream);
+int bdetr_rowchain_width(void);
+int64_t bdetr_rowchain_pack_elems(void);                 /* floats (4-byte units) of one packed copy of a 256 x 256 matrix */
+int bdetr_rowchain_partial_rows(int64_t M);
+/* table: device int64 [n][3] rows {W fp32 [256 out][256 in], forward copy | 0, backward copy | 0}; overflow_flag: the range guard
+ * (a weight whose 2^8 multiple leaves the f16 range raises it) */
+int bdetr_rowchain_pack_weights(const int64_t* table, int n, int* overflow_flag, void* stream);
+
 /* ------------------------------------------------------------------------
  * Panoptic head (forward only - the reference never wires it into a loss):
  * panoptic_neck.py:20-21 Resizing (bilinear, half-pixel centres), 118-121 / 164-167 channel LayerNormalization
