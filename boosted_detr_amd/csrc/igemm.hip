@@ -217,7 +217,12 @@ void igemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
     if (g.ngroups > 0) {
         // select with constant indices: a runtime index into kernel-argument arrays would push the whole
         // parameter block to scratch memory (measured: every igemm launch +25 %)
-        const int z = blockIdx.z;
+        // grouped AND split (the weight gradients of one layer's Dense kernels in one launch): blockIdx.z = group * splitk + slice
+        const int z = g.splitk > 1 ? (int)blockIdx.z / g.splitk : (int)blockIdx.z;
+        if (g.splitk > 1) {
+            r_begin = ((int)blockIdx.z - z * g.splitk) * g.r_chunk;
+            r_end = min(g.R, r_begin + g.r_chunk);
+        }
 #define BDETR_PICK(arr) (z == 0 ? g.arr[0] : z == 1 ? g.arr[1] : z == 2 ? g.arr[2] : g.arr[3])
         g.I = BDETR_PICK(gI); g.c = BDETR_PICK(gc); g.bias = BDETR_PICK(gbias);
         const float* pa = BDETR_PICK(ga);
@@ -588,7 +593,7 @@ int launch_cfg(const typename LA::Op& a, const typename LB::Op& b, GemmParams g,
     dim3 grid(g.tiles_i * g.tiles_j, 1, zdim);
     g.vec_store = (g.J % 4 == 0) && (g.ldc % 4 == 0) && (g.sc0 % 4 == 0) && (g.sc1 % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.c) & 15) == 0);
     const bool prof = g_prof_on;
-    if (prof) prof_begin(st, 2.0 * (double)g.I * (double)g.J * (double)g.R * (g.splitk > 1 ? 1.0 : (double)zdim), g.I, g.J, g.R, zdim, BM, BN,
+    if (prof) prof_begin(st, 2.0 * (double)g.I * (double)g.J * (double)g.R * (g.splitk > 1 ? (g.ngroups > 0 ? (double)g.ngroups : 1.0) : (double)zdim), g.I, g.J, g.R, zdim, BM, BN,
                          ARITH * 10000 + LoaderId<LA>::v * 1000 + (A_RC ? 100 : 0) + LoaderId<LB>::v * 10 + (B_RC ? 1 : 0));
     hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, LA, A_RC, LB, B_RC, ARITH>), grid, dim3(NTHREADS), 0, st, a, b, g);
     if (prof) prof_end(st);
@@ -735,7 +740,8 @@ extern "C" int bdetr_gemm_grouped(const bdetr_gemm_desc* d, int n, void* stream)
                         e.lda == d[0].lda && e.ldb == d[0].ldb && e.ldc == d[0].ldc,
                         "bdetr_gemm_grouped: problems must share J, R, leading dimensions, flavours and epilogue");
         BDETR_CHECK_ARG(e.grad == d[0].grad, "bdetr_gemm_grouped: problems must share the grad flag");
-        BDETR_CHECK_ARG((e.nb0 <= 1) && (e.nb1 <= 1) && e.splitk <= 1, "bdetr_gemm_grouped: no batching / split-K inside a group");
+        BDETR_CHECK_ARG((e.nb0 <= 1) && (e.nb1 <= 1) && e.splitk == d[0].splitk, "bdetr_gemm_grouped: no batching inside a group; one split-K factor for all problems");
+        BDETR_CHECK_ARG(e.splitk <= 1 || (!e.bias && e.act == 0 && e.I == d[0].I), "bdetr_gemm_grouped: split-K problems are plain GEMMs of one shape (C += partial products, atomics)");
         BDETR_CHECK_ARG(span_ok((int64_t)(e.a_rcontig ? e.I : e.R) * e.lda) && span_ok((int64_t)(e.b_rcontig ? e.J : e.R) * e.ldb),
                         "bdetr_gemm_grouped: operand %d spans 4 GB or more (32-bit buffer offsets)", k);
         g.ga[k] = e.a; g.gb[k] = e.b; g.gc[k] = e.c; g.gbias[k] = e.bias; g.gI[k] = e.I;
@@ -743,21 +749,33 @@ extern "C" int bdetr_gemm_grouped(const bdetr_gemm_desc* d, int n, void* stream)
         v4 = v4 && aligned16(e.a) && aligned16(e.b) && aligned16(e.c);
     }
     const bdetr_gemm_desc& f = d[0];
-    BDETR_CHECK_ARG(v4 && f.lda % 4 == 0 && f.ldb % 4 == 0 && f.ldc % 4 == 0 && f.J % 4 == 0 && f.R % 4 == 0,
-                    "bdetr_gemm_grouped: operands must be 16-byte aligned with dimensions that are multiples of 4");
+    // 16-byte loads run along an operand's contiguous index: r for an r-contiguous operand, i / j otherwise (a weight gradient's
+    // reduction index - the token count - is then free)
+    bool dims4 = f.J % 4 == 0 && (f.a_rcontig || f.b_rcontig ? f.R % 4 == 0 : true);
+    for (int k = 0; k < n; ++k) dims4 = dims4 && (f.a_rcontig || d[k].I % 4 == 0);
+    BDETR_CHECK_ARG(v4 && f.lda % 4 == 0 && f.ldb % 4 == 0 && f.ldc % 4 == 0 && dims4,
+                    "bdetr_gemm_grouped: operands must be 16-byte aligned with contiguous dimensions that are multiples of 4");
     g.ngroups = n;
     g.I = maxI; g.J = f.J; g.R = f.R;
     g.c = f.c; g.ldc = f.ldc; g.bias = f.bias; g.alpha = f.alpha; g.act = f.act;
     g.mode = f.accumulate ? ST_ACCUM : ST_STORE;
+    int zdim = n;
+    if (f.splitk > 1) {
+        // every problem's r range cut into the same slices; the slices add into C with float atomics (C zeroed by the caller)
+        g.r_chunk = (int)(cdiv64(cdiv64(f.R, f.splitk), BK) * BK);
+        g.splitk = (int)cdiv64(f.R, g.r_chunk);
+        g.mode = ST_ATOMIC;
+        zdim = n * g.splitk;
+    }
     DenseOp a{f.a, f.lda, 0, 0, f.a_rcontig ? maxI : f.R, f.a_rcontig ? f.R : maxI};
     DenseOp b{f.b, f.ldb, 0, 0, f.b_rcontig ? f.J : f.R, f.b_rcontig ? f.R : f.J};
     hipStream_t st = (hipStream_t)stream;
     const bool arc = f.a_rcontig != 0, brc = f.b_rcontig != 0;
     const int sp = use_split(f.grad != 0);
-    if (arc && brc)   return launch_any<DenseLoader<4>, true, DenseLoader<4>, true>(a, b, g, n, st, sp);
-    if (arc && !brc)  return launch_any<DenseLoader<4>, true, DenseLoader<4>, false>(a, b, g, n, st, sp);
-    if (!arc && !brc) return launch_any<DenseLoader<4>, false, DenseLoader<4>, false>(a, b, g, n, st, sp);
-    return launch_any<DenseLoader<4>, false, DenseLoader<4>, true>(a, b, g, n, st, sp, true);
+    if (arc && brc)   return launch_any<DenseLoader<4>, true, DenseLoader<4>, true>(a, b, g, zdim, st, sp);
+    if (arc && !brc)  return launch_any<DenseLoader<4>, true, DenseLoader<4>, false>(a, b, g, zdim, st, sp);
+    if (!arc && !brc) return launch_any<DenseLoader<4>, false, DenseLoader<4>, false>(a, b, g, zdim, st, sp);
+    return launch_any<DenseLoader<4>, false, DenseLoader<4>, true>(a, b, g, zdim, st, sp, true);
 }
 
 extern "C" int bdetr_gemm(const bdetr_gemm_desc* d, void* stream) { return bdetr_gemm_ws(d, nullptr, 0, stream); }

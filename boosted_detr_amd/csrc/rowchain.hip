@@ -179,7 +179,7 @@ __device__ __forceinline__ float tile_sum(const Tile& v) {
 }
 
 // x = LN(r + keep * y): y holds the Dense output on entry and the normalised row on exit, `s_out` the pre-norm sum
-__device__ __forceinline__ void add_drop_ln(Tile& y, const Tile& r, Tile& s_out, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+__device__ __forceinline__ void add_drop_ln(Tile& y, const Tile& r, Tile& s_out, const Tile& g, const Tile& b, float eps,
                                             float rate, uint64_t seed, float* red, const Lane& L, float& mean, float& rstd) {
     const uint32_t thresh = rate > 0.f ? (uint32_t)fminf(rate * 4294967296.0f, 4294967295.0f) : 0u;
     const float inv_keep = rate > 0.f ? 1.0f / (1.0f - rate) : 1.0f;
@@ -207,9 +207,6 @@ __device__ __forceinline__ void add_drop_ln(Tile& y, const Tile& r, Tile& s_out,
     dummy = 0.f;
     row_reduce2(qv, dummy, red + 2 * RNW * RBM, L);
     rstd = 1.0f / sqrtf(qv * (1.0f / RD) + eps);
-    Tile g, b;
-    vec_load(gamma, L, g);
-    vec_load(beta, L, b);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -270,17 +267,19 @@ __global__ __launch_bounds__(RNT) void rowchain_fwd_kernel(bdetr_rowchain_fwd_ar
     float mean, rstd;
     constexpr float WS = 1.0f / P16_W_SCALE;
     // ---- stage 1: output projection + Add + Dropout + LayerNorm ----
+    // (the epilogue's operands are requested BEFORE the K loop and pinned there: one workgroup per CU has nobody to hide a load
+    // behind, every round trip left in an epilogue is ~1 us of the launch)
+    Tile bia, gam, bet;
+    tile_load(a.resid, L, r);
+    vec_load(a.bias[0], L, bia); vec_load(a.g1, L, gam); vec_load(a.b1, L, bet);
+    __builtin_amdgcn_sched_barrier(0);
     gemm_stage<true>(w0, w1, lds, L, lane, ring, acc);
     tile_from_acc(acc, y);
-    {
-        Tile b; vec_load(a.bias[0], L, b);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) y[t][q] = y[t][q] * WS + b[t][q];
-    }
-    tile_load(a.resid, L, r);
-    add_drop_ln(y, r, s, a.g1, a.b1, a.eps, a.rate, seed1, red[0], L, mean, rstd);
+        for (int q = 0; q < 4; ++q) y[t][q] = y[t][q] * WS + bia[t][q];
+    add_drop_ln(y, r, s, gam, bet, a.eps, a.rate, seed1, red[0], L, mean, rstd);
     tile_store(a.pre1, L, s);
     tile_store(a.x1, L, y);
     if (L.wave == 0 && L.lh == 0 && L.ok) { a.mean1[L.m0 + L.j] = mean; a.rstd1[L.m0 + L.j] = rstd; }
@@ -289,34 +288,32 @@ __global__ __launch_bounds__(RNT) void rowchain_fwd_kernel(bdetr_rowchain_fwd_ar
     tile_to_lds<true>(lds, L, y);
     __syncthreads();
     // ---- stage 2: Dense + ReLU (x1 stays in `y`: the residual of stage 3) ----
+    vec_load(a.bias[1], L, bia);
+    __builtin_amdgcn_sched_barrier(0);
     gemm_stage<true>(w1, w2, lds, L, lane, ring, acc);
     Tile hh;
     tile_from_acc(acc, hh);
-    {
-        Tile b; vec_load(a.bias[1], L, b);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) hh[t][q][c] = fmaxf(hh[t][q][c] * WS + b[t][q][c], 0.f);
-    }
+            for (int c = 0; c < 4; ++c) hh[t][q][c] = fmaxf(hh[t][q][c] * WS + bia[t][q][c], 0.f);
     tile_store(a.h, L, hh);
     __syncthreads();                        // all waves are done reading x1's planes
     tile_to_lds<true>(lds, L, hh);
     __syncthreads();
     // ---- stage 3: Dense + Add + Dropout + LayerNorm ----
+    vec_load(a.bias[2], L, bia); vec_load(a.g2, L, gam); vec_load(a.b2, L, bet);
+    __builtin_amdgcn_sched_barrier(0);
     gemm_stage<true>(w2, w2, lds, L, lane, ring, acc);
     Tile f;
     tile_from_acc(acc, f);
-    {
-        Tile b; vec_load(a.bias[2], L, b);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) f[t][q] = f[t][q] * WS + b[t][q];
-    }
-    add_drop_ln(f, y, s, a.g2, a.b2, a.eps, a.rate, seed2, red[2], L, mean, rstd);
+        for (int q = 0; q < 4; ++q) f[t][q] = f[t][q] * WS + bia[t][q];
+    add_drop_ln(f, y, s, gam, bet, a.eps, a.rate, seed2, red[2], L, mean, rstd);
     tile_store(a.pre2, L, s);
     tile_store(a.x2, L, f);
     if (L.wave == 0 && L.lh == 0 && L.ok) { a.mean2[L.m0 + L.j] = mean; a.rstd2[L.m0 + L.j] = rstd; }
@@ -373,12 +370,8 @@ __device__ __forceinline__ void col_reduce_store(const Tile& v, float* __restric
 
 // LayerNorm backward of one row set: g = dout * gamma, xhat = (s - mean) * rstd, dh = (g - mean_f(g) - xhat * mean_f(g xhat)) * rstd.
 // Returns dh in `d` (in place), accumulates the column partial sums of dgamma / dbeta into dst.
-__device__ __forceinline__ void ln_bwd(Tile& d, const float* __restrict__ pre, const float* __restrict__ mean_p, const float* __restrict__ rstd_p,
-                                       const float* __restrict__ gamma, float* red, float* __restrict__ dgamma_part, float* __restrict__ dbeta_part, const Lane& L) {
-    Tile s, g;
-    tile_load(pre, L, s);
-    vec_load(gamma, L, g);
-    const float mean = L.ok ? mean_p[L.m0 + L.j] : 0.f, rstd = L.ok ? rstd_p[L.m0 + L.j] : 0.f;
+__device__ __forceinline__ void ln_bwd(Tile& d, const Tile& s, Tile& g, float mean, float rstd, float* red, float* __restrict__ dgamma_part,
+                                       float* __restrict__ dbeta_part, const Lane& L) {
     Tile xh, dg;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -437,9 +430,20 @@ __global__ __launch_bounds__(RNT) void rowchain_bwd_kernel(bdetr_rowchain_bwd_ar
     f32x16 acc[2];
     Tile d;                                  // the running gradient, in the lane's [feature][token] layout
     tile_load(a.dout, L, d);                 // (zeros for tokens beyond M: every partial sum below relies on that)
+    // saved tensors of the FIRST LayerNorm and the hidden activations: requested now, consumed after one or two K loops
+    Tile s1t, g1t, hh;
+    tile_load(a.pre1, L, s1t);
+    vec_load(a.g1, L, g1t);
+    const float mean1 = L.ok ? a.mean1[L.m0 + L.j] : 0.f, rstd1 = L.ok ? a.rstd1[L.m0 + L.j] : 0.f;
     if (a.nstages > 1) {
+        tile_load(a.h, L, hh);
+        Tile s2t, g2t;
+        tile_load(a.pre2, L, s2t);
+        vec_load(a.g2, L, g2t);
+        const float mean2 = L.ok ? a.mean2[L.m0 + L.j] : 0.f, rstd2 = L.ok ? a.rstd2[L.m0 + L.j] : 0.f;
+        __builtin_amdgcn_sched_barrier(0);
         // ---- LayerNorm 2 backward: dh2 -> residual branch (kept in `dres`) and, dropout-masked, the gradient of the second Dense ----
-        ln_bwd(d, a.pre2, a.mean2, a.rstd2, a.g2, red[0], part + 0 * RD, part + 1 * RD, L);
+        ln_bwd(d, s2t, g2t, mean2, rstd2, red[0], part + 0 * RD, part + 1 * RD, L);
         Tile dres;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -453,15 +457,12 @@ __global__ __launch_bounds__(RNT) void rowchain_bwd_kernel(bdetr_rowchain_bwd_ar
         // ---- dH = dF W2 (A = packed W2^T), ReLU mask from the saved hidden activations ----
         gemm_stage<false>(w2, w1, lds, L, lane, ring, acc);
         tile_from_acc(acc, d);
-        {
-            Tile hh; tile_load(a.h, L, hh);
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) d[t][q][c] = hh[t][q][c] > 0.f ? d[t][q][c] : 0.f;
-        }
+                for (int c = 0; c < 4; ++c) d[t][q][c] = hh[t][q][c] > 0.f ? d[t][q][c] : 0.f;
         tile_store(a.G1, L, d);
         col_reduce_store(d, part + 3 * RD, L);
         __syncthreads();                     // every wave has left the K loop
@@ -477,7 +478,7 @@ __global__ __launch_bounds__(RNT) void rowchain_bwd_kernel(bdetr_rowchain_bwd_ar
         __syncthreads();                     // (K loop done before the planes are rewritten below)
     }
     // ---- LayerNorm 1 backward: dh1 -> gradient of the residual input and, dropout-masked, of the output projection ----
-    ln_bwd(d, a.pre1, a.mean1, a.rstd1, a.g1, red[2], part + 4 * RD, part + 5 * RD, L);
+    ln_bwd(d, s1t, g1t, mean1, rstd1, red[2], part + 4 * RD, part + 5 * RD, L);
     tile_store(a.dresid, L, d);
     apply_keep(d, a.rate, seed1, L);
     tile_store(a.G0, L, d);

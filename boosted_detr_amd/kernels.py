@@ -568,6 +568,30 @@ def linear_bwd_weight(dy2d, x2d, dw=None, prezeroed: bool = False):
     return gemm_raw(O, K, M, dy2d, O, False, x2d, K, False, dw, K, splitk=sk, grad=True)
 
 
+def linear_bwd_weight_group(dys, xs, dws, prezeroed):
+    """dws[k][o][i] += sum_m dys[k][m][o] * xs[k][m][i] for up to 4 Dense layers of one shape in ONE split-K launch (float atomics);
+    prezeroed[k]: dws[k] already holds zeros or a running sum.  Deterministic mode and ragged groups fall back to one launch each."""
+    same = all(dy.shape == dys[0].shape and x.shape == xs[0].shape for dy, x in zip(dys, xs))
+    if _DETERMINISTIC[0] or not same or len(dys) == 1 or len(dys) > 4:
+        for dy, x, dw, pz in zip(dys, xs, dws, prezeroed):
+            linear_bwd_weight(dy, x, dw=dw, prezeroed=pz)
+        return dws
+    M, O = dys[0].shape
+    K_ = xs[0].shape[1]
+    L = _lib.lib()
+    for dw, pz in zip(dws, prezeroed):
+        if not pz:
+            check(L.bdetr_zero(_p(dw), dw.numel(), _stream()), "zero")
+    tiles = len(dys) * max(1, ((O + 63) // 64) * ((K_ + 63) // 64))
+    sk = max(1, min((2 * L.bdetr_device_cus()) // tiles, M // 128))
+    arr = (GemmDesc * len(dys))()
+    for k, (dy, x, dw) in enumerate(zip(dys, xs, dws)):
+        _chk(dy, x, dw)
+        arr[k] = GemmDesc(O, K_, M, 1, 1, _p(dy), O, 0, 0, 0, _p(x), K_, 0, 0, 0, _p(dw), K_, 0, 0, None, 1.0, ACT_NONE, 0, sk, 1)
+    check(L.bdetr_gemm_grouped(arr, len(dys), _stream()), "gemm_grouped(weight gradients)")
+    return dws
+
+
 def colsum(x2d, out=None, prezeroed=False):
     """Column sums.  prezeroed: `out` already holds zeros (a slice of the step's zero-filled flat gradient buffer) - one
     launch that adds with float atomics instead of the two-kernel deterministic reduction."""

@@ -509,18 +509,25 @@ def dense_group(xs, ws, bs):
 
     def backward(*gs):
         g2 = [_2d(g.contiguous()) for g in gs]
-        for g, x, w, b in zip(g2, x2, ws, bs):
-            if w.needs_grad or b.needs_grad:
-                def param_grads(g=g, x=x, w=w, b=b):
-                    if w.needs_grad:
-                        s = GradSink(w)
-                        K.linear_bwd_weight(g, x, dw=s.buf, prezeroed=s.mode == "direct")
-                        s.commit()
-                    if b.needs_grad:
-                        s = GradSink(b)
-                        K.colsum(g, out=s.buf, prezeroed=s.mode == "direct")
-                        s.commit()
-                side_task(param_grads, x, g)
+
+        def param_grads():
+            # weight gradients of the projections that share a shape go out as one grouped split-K launch (self-attention: all three;
+            # cross-attention: key + value, the query projection has its own row count)
+            groups = {}
+            for g, x, w in zip(g2, x2, ws):
+                if w.needs_grad:
+                    groups.setdefault((tuple(g.shape), tuple(x.shape)), []).append((g, x, GradSink(w)))
+            for members in groups.values():
+                K.linear_bwd_weight_group([m[0] for m in members], [m[1] for m in members], [m[2].buf for m in members], [m[2].mode == "direct" for m in members])
+                for m in members:
+                    m[2].commit()
+            for g, b in zip(g2, bs):
+                if b.needs_grad:
+                    s = GradSink(b)
+                    K.colsum(g, out=s.buf, prezeroed=s.mode == "direct")
+                    s.commit()
+        if any(w.needs_grad or b.needs_grad for w, b in zip(ws, bs)):
+            side_task(param_grads, *x2, *g2)
         dxs = K.linear_bwd_data_group(g2, [w.value for w in ws])
         return tuple(_own(dx.view(x.shape)) for dx, x in zip(dxs, xs))
 
@@ -742,11 +749,11 @@ def attention_out_chain(ctx: torch.Tensor, resid: torch.Tensor, out_proj, ln1, f
             for s_ in sinks:
                 if s_ is not None:
                     s_.commit()
-            for w, g, x in zip(ws, G, xs):
-                if w.needs_grad:
-                    s_ = GradSink(w)
-                    K.linear_bwd_weight(g, x, dw=s_.buf, prezeroed=s_.mode == "direct")
-                    s_.commit()
+            todo = [(w, g, x, GradSink(w)) for w, g, x in zip(ws, G, xs) if w.needs_grad]
+            if todo:                                           # the chain's weight gradients: one grouped split-K launch
+                K.linear_bwd_weight_group([t[1] for t in todo], [t[2] for t in todo], [t[3].buf for t in todo], [t[3].mode == "direct" for t in todo])
+                for t in todo:
+                    t[3].commit()
         side_task(param_grads, partials, *G, *xs)
         return _own(dctx.view(ctx.shape)), _own(dres.view(resid.shape))
 

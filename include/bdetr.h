@@ -270,7 +270,9 @@ int bdetr_gemm(const bdetr_gemm_desc* g, void* stream);
 int bdetr_gemm_ws(const bdetr_gemm_desc* g, float* ws, int64_t ws_elems, void* stream);
 /* n (1..4) independent GEMMs that share J, R, leading dimensions, operand flavours and epilogue flags
  * (their pointers, bias and row count I may differ) in ONE launch - the Q/K/V projections of an
- * attention block (transformers.py:68-70) and their input gradients.  No batching / split-K inside. */
+ * attention block (transformers.py:68-70) and their input gradients.  No batching inside.  splitk > 1 (the same value in every
+ * problem, problems of one shape, no bias / activation): every problem's r range is cut into the same slices, which ADD into C
+ * with float atomics (C zeroed by the caller) - the weight gradients of one layer's Dense kernels in one launch. */
 int bdetr_gemm_grouped(const bdetr_gemm_desc* g, int n, void* stream);
 
 /* column sums: out[j] = sum_i x[i][j]  (bias gradients; Keras autodiff of Dense/Conv bias).

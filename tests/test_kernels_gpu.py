@@ -383,3 +383,19 @@ def test_fused_attention_fwd_bwd(cuda, B, h, nq, nk, policy):
     close(dq, Qd.grad, rtol=bwd_tol)
     close(dk, Kd.grad, rtol=bwd_tol)
     close(dv, Vd.grad, rtol=bwd_tol)
+
+
+@pytest.mark.parametrize("M,n", [(6400, 3), (1600, 2), (300, 4)])
+def test_grouped_weight_gradients_in_one_split_k_launch(cuda, M, n):
+    """bdetr_gemm_grouped with splitk > 1: the weight gradients of n Dense layers of one shape (256 x 256, M tokens) in ONE launch, slices
+    adding with float atomics into zeroed / running-sum destinations."""
+    from boosted_detr_amd import kernels as k
+    dys = [rnd(M, 256, seed=10 + i) for i in range(n)]
+    xs = [rnd(M, 256, seed=20 + i) for i in range(n)]
+    base = [rnd(256, 256, seed=30 + i) if i == 0 else None for i in range(n)]            # the first destination holds a running sum
+    dws = [dev(b) if b is not None else torch.empty(256, 256).cuda() for b in base]
+    with k.gemm_precision("split"):
+        k.linear_bwd_weight_group([dev(t) for t in dys], [dev(t) for t in xs], dws, [b is not None for b in base])
+    for i in range(n):
+        want = dys[i].double().T @ xs[i].double() + (base[i].double() if base[i] is not None else 0)
+        close(dws[i], want, rtol=6e-5)
