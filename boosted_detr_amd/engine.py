@@ -389,6 +389,7 @@ class SegmentedCapture:
         self.mains, self.sides = [], []            # sides[i] (or None) runs behind mains[i]
         self.pending, self.done = [], []           # deferred side tasks of the open segment / closures kept alive until the end
         self._cur = None
+        self.in_side = False
 
     def begin_main(self) -> None:
         g = torch.cuda.CUDAGraph()
@@ -427,13 +428,17 @@ class SegmentedCapture:
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, pool=self.pool_side, stream=self.cap_side):
             prev = K.set_launch_stream(self.cap_side.cuda_stream)
+            self.in_side = True                   # (a data-parallel bucket completed by one of these tasks is captured here, inline)
             try:
-                for fn in self.pending:
-                    fn()
+                k = 0
+                while k < len(self.pending):      # a task may append one (training.DataParallel._launch from a main-segment gradient)
+                    self.pending[k]()
+                    k += 1
                 if _DEBUG_LOG[0] is not None:
                     from . import ops
                     _DEBUG_LOG[0].emit("S", ops._live_flat_grad[0])
             finally:
+                self.in_side = False
                 K.set_launch_stream(prev)
         self.sides.append(g)
         self.done.extend(self.pending)

@@ -188,6 +188,7 @@ class DataParallel:
         # stream, event waits, async handles - executes on the one-GPU box over a real "nccl" communicator of size 1)
         self.active = dist.is_initialized() and (self.world > 1 or os.environ.get("BDETR_DP_FORCE", "0") == "1")
         self._flat = None
+        self._expected = None            # contributions per variable and step (learnt from the first step on a flat buffer)
         self._comm_stream = None
         self.profile = False             # bench.py: time every bucket's all-reduce with events on the communication stream
         self._prof_events: List[tuple] = []
@@ -240,17 +241,35 @@ class DataParallel:
         self._launched = [False] * len(self._bounds)
         self._handles = []
         self._main, self._side = main_stream, side_stream
-        if self._comm_stream is None and self._flat.is_cuda:
+        from . import engine as _engine
+        capturing = _engine._CAPTURE[0] is not None
+        if self._comm_stream is None and self._flat.is_cuda and not capturing:
             self._comm_stream = torch.cuda.Stream(device=self._flat.device)
         self._prof_events = []
-        if self.profile and self._flat.is_cuda:
+        if self.profile and self._flat.is_cuda and not capturing:
             self._prof_base = torch.cuda.Event(enable_timing=True)
             self._prof_base.record(self._comm_stream)
         self._active = True
 
-    def _launch(self, b: int) -> None:
+    def _launch(self, b: int, inline: bool = False) -> None:
         lo, hi = self._bounds[b]
         self._launched[b] = True
+        from . import engine as _engine
+        cap = _engine._CAPTURE[0]
+        if cap is not None:
+            # The step is being captured as a chain of hipGraphs (Model._graph_step): the collective is captured too - RCCL kernels
+            # are graph nodes like any other.  A bucket completed by a main-segment kernel goes into the side graph that replays
+            # behind that segment (cap.pending: it then overlaps the next main segment like the weight-gradient GEMMs do); one
+            # completed by a side task is captured right there, inside the side graph; what finish() still has to send goes into the
+            # optimizer segment itself.  No communication stream, no handles: the graph's edges order everything.
+            flat, op = self._flat, self.dist.ReduceOp.SUM
+            fn = lambda: self.dist.all_reduce(flat[lo:hi], op=op)
+            if inline or getattr(cap, "in_side", False):
+                fn()
+            else:
+                cap.pending.append(fn)
+            self._captured_buckets = getattr(self, "_captured_buckets", 0) + 1
+            return
         if self._flat.is_cuda:
             # the bucket's gradients were written on the main stream (normalisation / bias gradients) and on the side
             # stream (weight-gradient GEMMs): the collective waits for both, neither of them waits for it
@@ -321,12 +340,14 @@ class DataParallel:
         self._active = False
         if self._expected is None:
             self._expected = dict(self._seen)
+        from . import engine as _engine
+        capturing = _engine._CAPTURE[0] is not None
         for b in range(len(self._bounds)):
             if not self._launched[b]:
-                self._launch(b)
+                self._launch(b, inline=True)
         for h in self._handles:
             h.wait()
-        if flat.is_cuda:
+        if flat.is_cuda and not capturing and self._comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self._comm_stream)
         self._handles = []
         if self.profile and self._prof_events:
@@ -601,8 +622,10 @@ class Model(Layer):
     # of graphs instead (engine.SegmentedCapture): the overlap is kept at segment granularity with a dozen cross-stream
     # events per step, and the step stays host-free.
     def _graph_signature(self, data: dict):
-        if not self.use_graph or self._dp is not None or self.validate_matching:
+        if not self.use_graph or self.validate_matching:
             return None
+        if self._dp is not None and (not getattr(self, "_dp_synced", True) or (self._dp.active and self._dp.overlap and self._dp._expected is None)):
+            return None          # replicas not yet broadcast / the bucket table not yet calibrated (its first eager step): not now
         from . import graph_replay_is_safe
         if not graph_replay_is_safe():
             if not getattr(self, "_graph_refused", False):
@@ -624,7 +647,9 @@ class Model(Layer):
         loss = tuple(getattr(lf, k, None) for k in ("category_weight", "attribute_weight", "box_weight", "exist_weight", "loss_scale"))
         opt = self.optimizer
         hyper = (opt.momentum, opt.nesterov, opt.clipnorm) if opt is not None else ()
-        return (id(opt), tuple(getattr(opt, "_built_for", None) or ()), tuple(id(v) for v in self.trainable_variables),
+        dp = self._dp
+        return (id(opt), (id(dp), dp.world, dp.active, dp.overlap) if dp is not None else None,
+                tuple(getattr(opt, "_built_for", None) or ()), tuple(id(v) for v in self.trainable_variables),
                 bool(self.guard_check_every), transformers.AttentionBlock.dropout_rate, transformers.FeedForwardBlock.dropout_rate, loss, hyper)
 
     def _device_step(self, data: dict, stage_scalars: bool) -> Dict[str, list]:

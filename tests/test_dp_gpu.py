@@ -248,5 +248,61 @@ def test_bench_multi_rank_code_path_over_one_rank_rccl(cuda):
     ar = line["allreduce"]
     assert ar and ar["buckets_per_step"] >= 3 and 120e6 < ar["bytes_per_step"] < 130e6 and ar["allreduce_ms_per_step"] > 0, ar       # 31.0 M fp32 gradients
     assert line["range_guard"]["overflow_flag_after_run"] == 0 and line["range_guard"]["range_redos_in_timed_region"] == 0
-    assert line["value"] > 100 and line["config"]["step_launch"] == "eager"
+    assert line["value"] > 100 and line["config"]["step_launch"] == "hipGraph replay (segmented)"      # N > 1 takes the headline's launch path (round 4)
     print({k: ar[k] for k in ("allreduce_ms_per_step", "algbw_GBps", "buckets_per_step")}, "images/s", line["value"])
+
+
+_WORKER_RCCL_GRAPH = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import boosted_detr_amd
+boosted_detr_amd.enable_graph_replay()
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from test_training_gpu import small_model, small_batch
+from boosted_detr_amd import kernels as K
+from boosted_detr_amd.engine import to_device
+from boosted_detr_amd.training import SGD, CosineDecayRestarts, DataParallel
+from oracle import detr_oracle as O
+K.set_deterministic(True)                                 # no float atomics: eager and replayed steps must agree to the last bit
+DataParallel.BUCKET_ELEMS = 1 << 19                       # several buckets on this toy (2 MB each)
+cfg, host = small_batch()
+params = O.make_params(cfg, seed=1)
+batch = {"image": to_device(host["image"]), "category": to_device(host["category"], torch.int32), "attribute": to_device(host["attribute"], torch.int32),
+         "bbox": to_device(host["bbox"]), "num_objects": to_device(host["num_objects"], torch.int32)}
+runs = {}
+for graph in (False, True):
+    m = small_model(dropout=0.1)
+    m.compile(optimizer=SGD(CosineDecayRestarts(1e-3, 10, m_mul=.95, alpha=.1), momentum=.9, nesterov=True, clipnorm=.1))
+    m.forward_backward(batch)
+    m.set_weights_dict(params)
+    m.distribute()
+    m.use_graph = graph
+    losses = [m.logs_to_host(m.train_step(batch))["loss"] for _ in range(8)]
+    for _ in range(4):
+        m.train_step(batch)                               # ... and four more without a host read in between
+    m.guard_flush(); torch.cuda.synchronize()
+    runs[graph] = (losses, m.get_weights_dict(), len(m._graphs), getattr(m._dp, "_captured_buckets", 0), len(m._dp._bounds))
+e, g = runs[False], runs[True]
+assert g[2] == 1 and g[3] >= g[4] >= 3 and e[2] == 0 and e[3] == 0, (g[2:], e[2:])      # every bucket's all-reduce is a node of the captured chain
+assert e[0] == g[0], (e[0], g[0])
+bad = [k for k in e[1] if not np.array_equal(e[1][k], g[1][k])]
+assert not bad, bad[:5]
+print("RCCL_GRAPH_DP_OK buckets", g[4], "captured all-reduces", g[3], "losses", g[0][:3])
+dist.destroy_process_group()
+'''
+
+
+def test_data_parallel_step_replays_as_hipgraphs_over_a_one_rank_rccl_communicator(cuda, tmp_path):
+    """The N > 1 step on the headline's launch path: the bucket all-reduces (and the guard's MAX all-reduce) are captured into the
+    chain of hipGraphs - a bucket completed on the main stream in the side graph behind that segment, one completed by a weight
+    gradient inside that side graph, the rest in the optimizer segment.  Over a real RCCL communicator of one rank (the box has one
+    GPU; BDETR_DP_FORCE=1 keeps the collectives on), deterministic mode: twelve replayed steps equal twelve eager data-parallel steps
+    bit for bit."""
+    script = tmp_path / "rccl_graph.py"
+    script.write_text(_WORKER_RCCL_GRAPH)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29557", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", BDETR_DP_FORCE="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0 and "RCCL_GRAPH_DP_OK" in p.stdout, p.stdout[-3000:]
+    print(p.stdout.strip().splitlines()[-1])
