@@ -16,7 +16,7 @@ from pathlib import Path
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB = CSRC / "libbdetr.so"
 OBJ_DIR = CSRC / "_obj"
-SOURCES = ["common.cpp", "igemm.hip", "sgemm.hip", "hconv.hip", "p16.hip", "attention.hip", "rowchain.hip", "augment.hip", "norm.hip", "elementwise.hip", "panoptic.hip", "matcher.hip", "optim.hip"]
+SOURCES = ["common.cpp", "igemm.hip", "sgemm.hip", "hconv.hip", "hwgrad.hip", "p16.hip", "attention.hip", "rowchain.hip", "augment.hip", "norm.hip", "elementwise.hip", "panoptic.hip", "matcher.hip", "optim.hip"]
 ARCH = "gfx950"
 COMMON_FLAGS = ["-O3", "-fPIC", f"--offload-arch={ARCH}", "-std=c++20", "-Wall", "-Wno-unused-function"] + os.environ.get("BDETR_CXXFLAGS", "").split()
 # the matcher must not contract a*b+c into fma (scipy / numpy evaluate unfused); see matcher.hip

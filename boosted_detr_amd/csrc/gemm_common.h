@@ -328,4 +328,9 @@ int splitk_fold(const float* ws, int zdim, int64_t slab, float* dst, int64_t n, 
 int hconv_tile(int64_t rows, int W, int C, int J, bool f16);          // BM * 1000 + BN, or 0: stay on sgemm.hip's im2col kernel
 int hconv_launch(int tile, bool f16, const void* x, int N, int H, int W, int C, const void* w, int J, const GemmParams& g, hipStream_t st);
 
+
+// ---- hwgrad.hip: 3x3 / stride 1 / pad 1 weight gradients with both operands resident in LDS as sliding pixel windows ----
+int hwgrad_slices(int N, int H, int W, int C, int K);                 // 0: not applicable (stay on sgemm.hip's im2col kernel), else the number of pixel slices
+int hwgrad_launch(const void* x_bf16, const void* dy_bf16, float* dw, int N, int H, int W, int C, int K, int slices, float* slabs, long long slab, int* zdim_out, hipStream_t st);
+
 }  // namespace bdgemm

@@ -1029,8 +1029,14 @@ static int wgrad_tile(const bdetr_conv_desc* d) {
     return T_128x128;
 }
 
+static bool is_3x3_same(const bdetr_conv_desc* d) { return d->R == 3 && d->S == 3 && d->stride == 1 && d->pad == 1; }
+
 extern "C" int bdetr_p16_conv2d_bwd_weight_splitk(const bdetr_conv_desc* d) {
     if (check_conv(d, "bdetr_p16_conv2d_bwd_weight_splitk")) return -1;
+    if (is_3x3_same(d)) {                                 // the halo-resident kernel (hwgrad.hip) slices the pixel range itself
+        const int hs = hwgrad_slices(d->N, d->H, d->W, d->C, d->K);
+        if (hs > 0) return hs > 1 ? hs : 2;               // (> 1: the slices add with atomics, the caller must hand over zeros / a running sum)
+    }
     const int M = d->N * d->OH * d->OW;
     const int64_t Kd = (int64_t)d->R * d->S * d->C;
     const int t = wgrad_tile(d);
@@ -1061,6 +1067,14 @@ static int p16_bwd_weight(const void* x_bf16, int x_is_f16, const void* dy_bf16,
     hipStream_t st = (hipStream_t)stream;
     const int M = d->N * d->OH * d->OW, Kd = d->R * d->S * d->C;
     if (splitk <= 0) splitk = bdetr_p16_conv2d_bwd_weight_splitk(d);
+    if (!x_is_f16 && is_3x3_same(d) && hwgrad_slices(d->N, d->H, d->W, d->C, d->K) > 0) {
+        // both operands as bf16 pairs, 3x3 'same': dy and x stream through LDS once for all nine taps (hwgrad.hip)
+        const int64_t n = (int64_t)d->K * Kd, slab = splitk_slab(n);
+        if (ws != nullptr) BDETR_CHECK_ARG(aligned16(ws) && ws_elems >= (int64_t)splitk * slab, "bdetr_p16_conv2d_bwd_weight_ws: workspace too small or misaligned");
+        int zdim = 1;
+        if (int e = hwgrad_launch(x_bf16, dy_bf16, dw, d->N, d->H, d->W, d->C, d->K, splitk, ws, slab, &zdim, st)) return e;
+        return ws != nullptr ? splitk_fold(ws, zdim, slab, dw, n, st) : 0;
+    }
     GemmParams g; init_params(g);
     g.b_f16 = x_is_f16;
     g.I = d->K; g.J = Kd; g.R = M;
