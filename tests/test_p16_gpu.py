@@ -322,3 +322,18 @@ def test_p16_forward_on_small_activations(cuda, rms):
     err = (y.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
     bound = max(2e-5, 4 * 2.0 ** -25 / rms)
     assert err <= bound, (err, bound)
+
+
+def test_halo_resident_weight_gradient_kernel_matches_too(cuda):
+    """csrc/hwgrad.hip (3x3 weight gradients with both operands as sliding LDS windows) is off by default - it measured slower than
+    the im2col kernel (profiles/r04_hwgrad_ab.json) - but stays correct: the same conv cases, fp64 references and deterministic-mode
+    checks with BDETR_HWGRAD=1 (read once per process, hence the child process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BDETR_HWGRAD="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_p16_gpu.py"), "-q", "-x", "-k",
+                        "test_p16_conv_fwd_bwd and (40-40-256 or 20-20-512 or 80-80-128 or 14-14-256)"], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-1000:]
+    assert int(r.stdout.strip().splitlines()[-1].split(" passed")[0].split()[-1]) >= 4, r.stdout[-500:]
