@@ -39,7 +39,8 @@ class BnAffine(C.Structure):
 
 class BnBwdFuse(C.Structure):
     _fields_ = [("y", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("relu", C.c_int),
-                ("part_g", C.c_void_p), ("part_gx", C.c_void_p), ("relu_mask", C.c_void_p)]
+                ("part_g", C.c_void_p), ("part_gx", C.c_void_p), ("relu_mask", C.c_void_p),
+                ("y2", C.c_void_p), ("mean2", C.c_void_p), ("rstd2", C.c_void_p), ("part_gx2", C.c_void_p)]
 
 
 class RowchainFwdDesc(C.Structure):

@@ -35,6 +35,10 @@ struct GemmParams {
     const float* bnb_y; const float* bnb_mean; const float* bnb_rstd; const float* bnb_gamma; const float* bnb_beta;
     int bnb_relu; float* bnb_sum_g; float* bnb_sum_gx;
     const unsigned long long* bnb_mask;      // (sgemm's dense 1x1 kernels, with acc_mask) the ReLU decision comes from these bits, not from recomputing it
+    // A SECOND BatchNorm that shares the gradient g (the projection shortcut's: out = relu(bn3(y3) + bn0(y0)), round 4): its sum of g is the
+    // first one's, only sum(g * xhat0) is new - one more read of y0 here instead of a reduction pass over (g, bits, y0) of its own.
+    // Masked-accumulate + masked-sums launches only.
+    const float* bnb2_y; const float* bnb2_mean; const float* bnb2_rstd; float* bnb2_sum_gx;
     // ST_ACCUM with acc_mask set (sgemm's dense 1x1 kernels only): C = product + C * bit, bit = bn_apply_p16's 1-bit
     // ReLU mask of the element (norm.hip relu_mask_bits4 layout) - the skip branch of a residual unit merged without ever
     // materialising its masked gradient
@@ -145,7 +149,7 @@ __device__ __forceinline__ unsigned mask_bits4(const unsigned long long* mask, i
 // statistics (above), then either LDS-transposed 16-byte row stores (store / accumulate) or per-element stores /
 // atomics (split-K).  `lds` must hold LDS_FLOATS >= BM * BN floats and be free to overwrite once every wave has
 // passed the barrier this function starts with.
-template <int BM, int BN, int WM, int WN, int NT, int LDS_FLOATS, bool MASKED_VARIANTS = false>
+template <int BM, int BN, int WM, int WN, int NT, int LDS_FLOATS, bool MASKED_VARIANTS = false, bool BNB2_ONLY = false>
 __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], const GemmParams& g, float* lds,
                                               int tile_i, int i0, int j0, float* cbase, const float* bias_pre = nullptr) {
     constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
@@ -192,11 +196,18 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
         // still without its ReLU mask - C = product + old * bit (g.acc_mask) - and, with BNB, the ReLU decision of the fused sums
         // comes from g.bnb_mask instead of being recomputed.  Accumulate + sums together keep three float4 per row group alive
         // (product, old, y): that combination runs the tile in two halves so that it stays inside 256 VGPRs.
-        auto vec_out = [&](auto rowmap_c, auto accum_c, auto bnb_c, auto masked_c) {
+        auto vec_out = [&](auto rowmap_c, auto accum_c, auto bnb_c, auto masked_c, auto bnb2_c) {
             constexpr bool ROWMAP = decltype(rowmap_c)::value, ACCUM = decltype(accum_c)::value, BNB = decltype(bnb_c)::value, MASKED = decltype(masked_c)::value;
-            constexpr int NPART = (ACCUM && BNB) ? 2 : 1, PIT = ITERS / NPART;
+            constexpr bool BNB2 = decltype(bnb2_c)::value;         // + sum(g * xhat) of a second BatchNorm over the same g (bnb2_*)
+            static_assert(!BNB2 || (BNB && ACCUM && MASKED), "the second BatchNorm rides the masked accumulate with masked sums");
+            constexpr int NPART = (ACCUM && BNB) ? (BNB2 && ITERS % 4 == 0 ? 4 : 2) : 1, PIT = ITERS / NPART;
             static_assert(ITERS % NPART == 0, "the tile splits into equal parts");
             f32x4 bnv[BNB ? 6 : 1];                       // mean, rstd, gamma, beta of the thread's 4 columns; running sums of g, g * xhat
+            f32x4 bn2[BNB2 ? 3 : 1];                      // mean, rstd of the second BatchNorm; running sum of g * xhat2
+            if constexpr (BNB2) {
+                bn2[0] = f32x4{0, 0, 0, 0}; bn2[1] = f32x4{0, 0, 0, 0}; bn2[2] = f32x4{0, 0, 0, 0};
+                if (jok) { bn2[0] = *reinterpret_cast<const f32x4*>(g.bnb2_mean + jc); bn2[1] = *reinterpret_cast<const f32x4*>(g.bnb2_rstd + jc); }
+            }
             if constexpr (BNB) {
 #pragma unroll
                 for (int q = 0; q < 6; ++q) bnv[q] = f32x4{0, 0, 0, 0};
@@ -207,7 +218,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
             }
 #pragma unroll
             for (int part = 0; part < NPART; ++part) {
-                f32x4 val[PIT], old[ACCUM ? PIT : 1], yv[BNB ? PIT : 1];
+                f32x4 val[PIT], old[ACCUM ? PIT : 1], yv[BNB ? PIT : 1], y2v[BNB2 ? PIT : 1];
                 unsigned abits[(ACCUM && MASKED) ? PIT : 1], bbits[(BNB && MASKED) ? PIT : 1];
                 float* dst[PIT];
                 bool ok[PIT];
@@ -224,6 +235,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
                     if constexpr (ACCUM && MASKED) { abits[k] = 0u; if (ok[k]) abits[k] = mask_bits4(g.acc_mask, (row * g.ldc + jc) >> 2); }
                     if constexpr (BNB) { yv[k] = f32x4{0, 0, 0, 0}; if (ok[k]) yv[k] = *reinterpret_cast<const f32x4*>(g.bnb_y + (int64_t)i * g.ldc + jc); }
                     if constexpr (BNB && MASKED) { bbits[k] = 0u; if (ok[k]) bbits[k] = mask_bits4(g.bnb_mask, ((int64_t)i * g.ldc + jc) >> 2); }
+                    if constexpr (BNB2) { y2v[k] = f32x4{0, 0, 0, 0}; if (ok[k]) y2v[k] = *reinterpret_cast<const f32x4*>(g.bnb2_y + (int64_t)i * g.ldc + jc); }
                 }
 #pragma unroll
                 for (int k = 0; k < PIT; ++k) {
@@ -245,6 +257,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
                             else on = !g.bnb_relu || (__builtin_fmaf(yv[k][e] - bnv[0][e], bnv[1][e] * bnv[2][e], bnv[3][e]) > 0.f);      // = norm.hip's bn_affine
                             const float ge = on ? val[k][e] : 0.f;
                             bnv[4][e] += ge; bnv[5][e] += ge * ((yv[k][e] - bnv[0][e]) * bnv[1][e]);
+                            if constexpr (BNB2) bn2[2][e] += ge * ((y2v[k][e] - bn2[0][e]) * bn2[1][e]);
                         }
                     }
                 }
@@ -266,21 +279,36 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
                     *reinterpret_cast<f32x4*>(g.bnb_sum_g + (int64_t)tile_i * g.J + jc) = a;
                     *reinterpret_cast<f32x4*>(g.bnb_sum_gx + (int64_t)tile_i * g.J + jc) = b;
                 }
+                if constexpr (BNB2) {                                 // the same fold for the second BatchNorm's sum
+                    __syncthreads();
+                    *reinterpret_cast<f32x4*>(lds + tid * 4) = bn2[2];
+                    __syncthreads();
+                    if (tid < V_PER_ROW && jok) {
+                        f32x4 c = {0, 0, 0, 0};
+#pragma unroll
+                        for (int k = 0; k < RSTEP; ++k) c += *reinterpret_cast<const f32x4*>(lds + (tid + k * V_PER_ROW) * 4);
+                        *reinterpret_cast<f32x4*>(g.bnb2_sum_gx + (int64_t)tile_i * g.J + jc) = c;
+                    }
+                }
             }
         };
         using T = std::true_type; using F = std::false_type;
         const bool accum = g.mode == ST_ACCUM;
         // host contracts: fused sums never come with a row map; a masked accumulate comes with masked sums or with none
+        // (the second-BatchNorm form lives in a kernel instantiation of its own - sgemm.hip EPI_BNB2 - so that its extra float4 array
+        // does not cost the other variants of the shared kernel registers: compiled in next to them it took their spills from 13 to 40)
+        if constexpr (BNB2_ONLY) { vec_out(F{}, T{}, T{}, T{}, T{}); return; }
         if constexpr (MASKED_VARIANTS) {
             if (g.acc_mask != nullptr) {
-                if (g.bnb_y != nullptr) vec_out(F{}, T{}, T{}, T{}); else vec_out(F{}, T{}, F{}, T{});
+                if (g.bnb_y != nullptr) vec_out(F{}, T{}, T{}, T{}, F{});
+                else vec_out(F{}, T{}, F{}, T{}, F{});
                 return;
             }
         }
-        if (g.bnb_y != nullptr) vec_out(F{}, F{}, T{}, F{});
-        else if (g.rowmap) { if (accum) vec_out(T{}, T{}, F{}, F{}); else vec_out(T{}, F{}, F{}, F{}); }
-        else if (accum) vec_out(F{}, T{}, F{}, F{});
-        else vec_out(F{}, F{}, F{}, F{});
+        if (g.bnb_y != nullptr) vec_out(F{}, F{}, T{}, F{}, F{});
+        else if (g.rowmap) { if (accum) vec_out(T{}, T{}, F{}, F{}, F{}); else vec_out(T{}, F{}, F{}, F{}, F{}); }
+        else if (accum) vec_out(F{}, T{}, F{}, F{}, F{});
+        else vec_out(F{}, F{}, F{}, F{}, F{});
         return;
     }
     // per-element stores / accumulates / atomics (split-K, or rows that are not 16-byte aligned): the mode is hoisted too

@@ -188,7 +188,7 @@ constexpr int lds_bytes_for(int bm, int bn, int ns) { return ns * (bm + bn) * 12
 // runs.  The buffer descriptor covers exactly the tile's valid rows (rows past I are dropped by the buffer unit's range
 // check), a lane's column is valid or not for the whole tile (an invalid one starts 2 GB out of range), and the row
 // offset is one running VGPR: a store costs one add, and the second 32-column block rides the instruction's immediate.
-enum { EPI_PLAIN = 0, EPI_ROWMAP = 1, EPI_VEC = 8 };
+enum { EPI_PLAIN = 0, EPI_ROWMAP = 1, EPI_VEC = 8, EPI_BNB2 = 16 };      // EPI_BNB2 (with EPI_VEC): only the masked accumulate + masked sums + second-BatchNorm sum form
 template <int BM, int BN, int WM, int WN, bool STATS = true, int EPI = EPI_ROWMAP>
 __device__ __forceinline__ void direct_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], const GemmParams& g, int tile_i, int i0, int j0, const float* bias_pre) {
     constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
@@ -706,7 +706,7 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
             atomic_epilogue<BM, BN, WM, WN>(acc, g, i0, j0);
             return;
         }
-        gemm_epilogue<BM, BN, WM, WN, NT, LDS_BYTES / 4, (EPI & EPI_VEC) != 0>(acc, g, reinterpret_cast<float*>(lds), tile_i, i0, j0, g.c + (g.splitk > 1 ? (int64_t)zz * g.sc0 : 0), bias_pre);
+        gemm_epilogue<BM, BN, WM, WN, NT, LDS_BYTES / 4, (EPI & EPI_VEC) != 0, (EPI & EPI_BNB2) != 0>(acc, g, reinterpret_cast<float*>(lds), tile_i, i0, j0, g.c + (g.splitk > 1 ? (int64_t)zz * g.sc0 : 0), bias_pre);
     }
 }
 
@@ -789,6 +789,7 @@ int launch_cfg(const typename LA::Op& a, const typename LB::Op& b, GemmParams g,
             BDETR_CHECK_ARG(g.vec_store, "sgemm: accumulate / fused BatchNorm-backward sums need 16-byte aligned C rows and J %% 4 == 0");
             BDETR_CHECK_ARG(g.acc_mask == nullptr || g.mode == ST_ACCUM, "sgemm: acc_mask without accumulate");
             BDETR_CHECK_ARG(g.bnb_mask == nullptr || (g.acc_mask != nullptr && g.bnb_y != nullptr), "sgemm: a bit-mask ReLU decision comes with a masked accumulate");
+            if (g.bnb2_y != nullptr) return go(std::integral_constant<int, EPI_VEC | EPI_BNB2>{});
             return go(std::integral_constant<int, EPI_VEC>{});
         }
         BDETR_CHECK_ARG(g.acc_mask == nullptr && g.bnb_y == nullptr, "sgemm: masks / fused sums are not available with a row map");
@@ -973,6 +974,11 @@ static int p16_bwd_data(const void* dy_bf16, const void* wt_bf16, float* dx, con
         g.bnb_y = bn->y; g.bnb_mean = bn->mean; g.bnb_rstd = bn->rstd; g.bnb_gamma = bn->gamma; g.bnb_beta = bn->beta;
         g.bnb_relu = bn->relu; g.bnb_sum_g = bn->part_g; g.bnb_sum_gx = bn->part_gx;
         g.bnb_mask = reinterpret_cast<const unsigned long long*>(bn->relu_mask);
+        if (bn->y2 != nullptr) {
+            BDETR_CHECK_ARG(acc_mask != nullptr && bn->relu_mask != nullptr && bn->mean2 && bn->rstd2 && bn->part_gx2 && aligned16(bn->y2),
+                            "bdetr_p16_conv2d_bwd_data_masked_accum: the second BatchNorm's sums ride a masked accumulate with masked sums");
+            g.bnb2_y = bn->y2; g.bnb2_mean = bn->mean2; g.bnb2_rstd = bn->rstd2; g.bnb2_sum_gx = bn->part_gx2;
+        }
     }
     if (d->R == 1 && d->S == 1 && d->pad == 0) {
         g.I = M; g.J = d->C; g.R = d->K;

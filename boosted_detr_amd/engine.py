@@ -234,6 +234,8 @@ class Tape:
                     # produced it: ops.conv_bn) describe the tensor BEFORE this contribution: drop them
                     if hasattr(have, "_bnb_parts"):
                         del have._bnb_parts
+                    if hasattr(have, "_bnb_parts_shortcut"):
+                        del have._bnb_parts_shortcut
                     if getattr(have, "_bdetr_owned", False):       # sole owner: accumulate in place
                         K.axpy_(1.0, g.view(have.shape), have)
                     else:

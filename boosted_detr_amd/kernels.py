@@ -433,7 +433,7 @@ def relu_mask_apply_(x: torch.Tensor, relu_mask: torch.Tensor) -> torch.Tensor:
     return x
 
 
-def p16_conv2d_bwd_data_masked_accum(dy_bf16, wt_bf16, g: ConvGeom, dx: torch.Tensor, relu_mask: torch.Tensor, bn_ctx=None):
+def p16_conv2d_bwd_data_masked_accum(dy_bf16, wt_bf16, g: ConvGeom, dx: torch.Tensor, relu_mask: torch.Tensor, bn_ctx=None, bn_ctx2=None):
     """dx (the gradient of a residual unit's output on entry) <- conv_transpose(dy) + dx * relu_mask, in place: the unit's skip
     branch merged inside the 1x1 backward-data epilogue of its first convolution.  bn_ctx = (y_prev, mean, rstd, gamma, beta,
     relu_mask_prev): the result is the complete output gradient of the PREVIOUS residual unit - also emit that unit's
@@ -454,8 +454,18 @@ def p16_conv2d_bwd_data_masked_accum(dy_bf16, wt_bf16, g: ConvGeom, dx: torch.Te
         check(-1, "p16_conv2d_bwd_data_stat_chunks")
     pg, pgx = empty(n, g.C, like=dy_bf16), empty(n, g.C, like=dy_bf16)
     f = BnBwdFuse(_p(y_prev), _p(mean), _p(rstd), _p(gamma), _p(beta), 1, _p(pg), _p(pgx), _p(bits_prev))
+    pgx2 = None
+    if bn_ctx2 is not None:
+        # the previous unit is a stage's FIRST one: its projection shortcut's BatchNorm sees the same gradient - (y0, mean0, rstd0):
+        # also emit that BatchNorm's sum(g * xhat0); returns ((part_g, part_gx, n), (part_g, part_gx0, n))
+        y0, mean0, rstd0 = bn_ctx2
+        _chk(y0, mean0, rstd0)
+        pgx2 = empty(n, g.C, like=dy_bf16)
+        f.y2, f.mean2, f.rstd2, f.part_gx2 = _p(y0), _p(mean0), _p(rstd0), _p(pgx2)
     check(L.bdetr_p16_conv2d_bwd_data_masked_accum(_p(dy_bf16), _p(wt_bf16), _p(dx), _p(relu_mask), C.byref(d), C.byref(f), _stream()),
           "p16_conv2d_bwd_data_masked_accum")
+    if pgx2 is not None:
+        return dx, (pg, pgx, n), (pg, pgx2, n)
     return dx, (pg, pgx, n)
 
 

@@ -282,6 +282,10 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
             out._p16f, out._p16b, out._p16_only = of.view(out.shape), (ob.view(out.shape) if ob is not None else None), not fp32_out
         if relu_bits is not None and sole_consumer_is_identity_unit and os.environ.get("BDETR_BN_FUSE", "1") != "0":
             out._bn_ctx_bits = (y2d, mean, rstd, bn.gamma.value, bn.beta.value, relu_bits)
+            if res_bn is not None and os.environ.get("BDETR_BN_FUSE2", "1") != "0":
+                # a stage's first unit: the projection shortcut's BatchNorm (deferred: res2d is its RAW conv output) gets the same gradient -
+                # its sum(g * xhat0) rides the same epilogue (round 4)
+                out._bn_ctx_bits2 = (res2d, res_bn[0], res_bn[1])
         if not fp32_out and residual is None and os.environ.get("BDETR_BN_FUSE", "1") != "0":
             # a link with exactly one consumer (the next conv of the bottleneck): that conv's backward-data epilogue can do
             # THIS BatchNorm's backward reduction while it stores the gradient (ops: see `backward` below)
@@ -325,6 +329,9 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
             if lazy_skip:
                 dres = _own(g_out.view(residual.shape))
                 dres._lazy_mask = relu_bits
+                sc_parts = getattr(g_out, "_bnb_parts_shortcut", None)
+                if sc_parts is not None and res_bn is not None:
+                    dres._bnb_parts = sc_parts          # the shortcut's BatchNorm backward finds its reduction done (it reads them as `pre`)
             sg.commit()
             sb.commit()
             dyb4 = dyb.view(N, g.OH, g.OW, Kout)
@@ -351,8 +358,11 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
                     if skip_bits is not None and R == 1 and S == 1 and stride == 1 and pad == 0:
                         ctx_bits = getattr(x_handle, "_bn_ctx_bits", None)
                         if ctx_bits is not None:        # this merge completes the previous unit's output gradient: do its BN-backward sums too
-                            _, parts = K.p16_conv2d_bwd_data_masked_accum(dyb4, wt, g, acc[0].view(N, H, W, Cin), skip_bits, bn_ctx=ctx_bits)
-                            acc[0]._bnb_parts = parts
+                            ctx2 = getattr(x_handle, "_bn_ctx_bits2", None)
+                            r = K.p16_conv2d_bwd_data_masked_accum(dyb4, wt, g, acc[0].view(N, H, W, Cin), skip_bits, bn_ctx=ctx_bits, bn_ctx2=ctx2)
+                            acc[0]._bnb_parts = r[1]
+                            if ctx2 is not None:
+                                acc[0]._bnb_parts_shortcut = r[2]      # ... and those of its projection shortcut's BatchNorm
                         else:
                             K.p16_conv2d_bwd_data_masked_accum(dyb4, wt, g, acc[0].view(N, H, W, Cin), skip_bits)
                         del acc[0]._lazy_mask

@@ -220,6 +220,10 @@ typedef struct {
     const float* y; const float* mean; const float* rstd; const float* gamma; const float* beta; int relu;
     float* part_g; float* part_gx;
     const uint64_t* relu_mask;      /* may be null; else out = relu(bn(y) + shortcut): the ReLU decision is bdetr_bn_apply_p16's bit mask (1x1 convs only) */
+    /* A second BatchNorm over the SAME gradient (may be null; bdetr_p16_conv2d_bwd_data_masked_accum with relu_mask only): the projection
+     * shortcut of a stage's first unit, out = relu(bn3(y3) + bn0(y0)) (keras.applications.resnet block1 with conv_shortcut, reference
+     * backbone.py:37-38).  Its sum of g is part_g; part_gx2 receives its sum of g * xhat0, xhat0 = (y2 - mean2) * rstd2. */
+    const float* y2; const float* mean2; const float* rstd2; float* part_gx2;
 } bdetr_bn_bwd_fuse;
 int bdetr_p16_conv2d_bwd_data_stat_chunks(const bdetr_conv_desc* d);
 /* x <- x * relu_mask in place (n elements, n % 4 == 0): materialises a gradient that was handed on with its unit's ReLU mask

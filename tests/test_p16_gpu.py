@@ -301,6 +301,18 @@ def test_masked_accumulate_also_reduces_the_previous_units_batchnorm_backward(cu
     got = k.bn_bwd_p16(dx.view(rows, C), bits, y, mean, rstd, gamma, True, False, beta=beta, want_fp32=True, out_p16=2, pre=parts)
     close(got[2], ref[2], rtol=1e-5); close(got[3], ref[3], rtol=1e-5)          # dgamma, dbeta
     close(got[1], ref[1], rtol=1e-5)                                             # dx of the BatchNorm
+    # ... and, when the previous unit is a stage's first one, the sums of its PROJECTION SHORTCUT's BatchNorm over the same masked
+    # gradient (round 4): same dx, same first sums, and bn_bwd_p16 of the shortcut's BatchNorm (ReLU decision = the unit's bits,
+    # out_p16 = 2) fed with the second pair agrees with its own reduction pass
+    y0 = dev(rnd(rows, C, seed=31) * 1.5 - 0.2)
+    g0 = dev(1 + 0.1 * rnd(C, seed=32))
+    b0 = dev(0.1 * rnd(C, seed=33))
+    mean0, rstd0 = k.bn_stats(rows, C, k.colstats(y0), 1.001e-5, 0.99, True, dev(torch.zeros(C)), dev(torch.ones(C)), like=y0)
+    dx2, parts_a, parts_b = k.p16_conv2d_bwd_data_masked_accum(dyb, wt, g, dev(d_out), this[5], bn_ctx=prev, bn_ctx2=(y0, mean0, rstd0))
+    assert torch.equal(dx2, plain) and torch.equal(parts_a[0], parts[0]) and torch.equal(parts_a[1], parts[1]) and parts_b[0] is parts_a[0]
+    ref0 = k.bn_bwd_p16(dx.view(rows, C), bits, y0, mean0, rstd0, g0, True, False, beta=b0, want_fp32=True, out_p16=2)
+    got0 = k.bn_bwd_p16(dx.view(rows, C), bits, y0, mean0, rstd0, g0, True, False, beta=b0, want_fp32=True, out_p16=2, pre=parts_b)
+    close(got0[2], ref0[2], rtol=1e-5); close(got0[3], ref0[3], rtol=1e-5); close(got0[1], ref0[1], rtol=1e-5)
 
 
 @pytest.mark.parametrize("rms", [1e-3, 1e-5])
