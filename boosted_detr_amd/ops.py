@@ -746,7 +746,43 @@ def attention_out_chain(ctx: torch.Tensor, resid: torch.Tensor, out_proj, ln1, f
                            (ffn[4].value, ffn[5].value) if ffn is not None else None, eps, r, seed1, seed2, base)
     out = (saved["x2"] if ffn is not None else saved["x1"]).view(resid.shape)
 
+    def backward_unfused(g_out):
+        """The same backward on the separate kernels, from the tensors the fused forward saved - taken when the backward runs under
+        another arithmetic policy than the forward did (Model.replay_backward('fp32'): exact-fp32 gradient products)."""
+        g2 = _2d(g_out.contiguous())
+        zeros = torch.zeros_like(ctx2d)                   # add_dropout_layernorm_bwd recomputes x + keep * y: x = the saved sum, y = 0
+        todo = []
+        if ffn is not None:
+            W1, bb1, W2, bb2, g2v, b2v = ffn
+            sg, sb = GradSink(g2v), GradSink(b2v)
+            dh2, df, _, _ = K.add_dropout_layernorm_bwd(g2, saved["pre2"], zeros, g2v.value, saved["mean2"], saved["rstd2"], r, seed2,
+                                                        dgamma=sg.buf, dbeta=sb.buf, seed_base=base)
+            sg.commit(); sb.commit()
+            dpre1 = K.relu_bwd(saved["h"], K.linear_bwd_data(df, W2.value))
+            dx1 = K.linear_bwd_data(dpre1, W1.value, dx=dh2, accumulate=True)
+            todo += [(W2, bb2, df, saved["h"]), (W1, bb1, dpre1, saved["x1"])]
+        else:
+            dx1 = g2
+        sg, sb = GradSink(g1), GradSink(b1)
+        dres, da, _, _ = K.add_dropout_layernorm_bwd(dx1, saved["pre1"], zeros, g1.value, saved["mean1"], saved["rstd1"], r, seed1,
+                                                    dgamma=sg.buf, dbeta=sb.buf, seed_base=base)
+        sg.commit(); sb.commit()
+        dctx = K.linear_bwd_data(da, Wo.value)
+        todo.append((Wo, bo, da, ctx2d))
+        for w, b, g, x in todo:
+            if w.needs_grad:
+                s_ = GradSink(w)
+                K.linear_bwd_weight(g, x, dw=s_.buf, prezeroed=s_.mode == "direct")
+                s_.commit()
+            if b.needs_grad:
+                s_ = GradSink(b)
+                K.colsum(g, out=s_.buf, prezeroed=s_.mode == "direct")
+                s_.commit()
+        return _own(dctx.view(ctx.shape)), _own(dres.view(resid.shape))
+
     def backward(g_out):
+        if K.get_gemm_precision() != "split":
+            return backward_unfused(g_out)
         gammas = (g1.value,) + ((ffn[4].value,) if ffn is not None else ())
         packs_t = [_RC_PACKED.get(w)[1] for w in ws]
         dctx, dres, G, partials, nparts = K.rowchain_bwd(_2d(g_out.contiguous()), saved, packs_t, gammas, r, seed1, seed2, base)

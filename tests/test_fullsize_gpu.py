@@ -59,6 +59,30 @@ def test_config2_batch2_matches_oracle(cuda):
     # every trainable tensor against the fp64 oracle (relative L2, next to the fp32 oracle's own error)
     from test_model_gpu import check_grads
     check_grads(model, cfg, params, batch, g32=grads, g64=g64)
+    # The headline's gradient arithmetic (bf16 pairs, 2^-18 per product) against the reference's (exact fp32 products), per tensor, against
+    # the fp64 oracle: both backward passes start from the SAME saved forward (same activations, ReLU masks, match), so the difference is
+    # the gradient products alone.  Bound: the split policy's error is at most twice the fp32 policy's (+ 1e-4 of the
+    # tensor's norm: below that both are round-off of different summation orders).
+    model.forward_backward(batch, keep_tape=True)
+    model.replay_backward("split")
+    g_split = {v.name: v.grad_numpy().astype(np.float64) for v in model.trainable_variables}
+    model.replay_backward("fp32")
+    g_fp32 = {v.name: v.grad_numpy().astype(np.float64) for v in model.trainable_variables}
+    model._kept_tape = None
+    gmax = max(np.abs(g).max() for g in g64.values())
+    rows = []
+    for name, ref in g64.items():
+        ref = np.asarray(ref, np.float64)
+        if name not in g_split or np.abs(ref).max() < 1e-6 * gmax:
+            continue
+        nrm = np.linalg.norm(ref)
+        e_s, e_f = np.linalg.norm(g_split[name].reshape(ref.shape) - ref) / nrm, np.linalg.norm(g_fp32[name].reshape(ref.shape) - ref) / nrm
+        rows.append((e_s / max(e_f, 1e-12), e_s, e_f, name))
+        assert e_s <= 2.0 * e_f + 1e-4, (name, e_s, e_f)
+    rows.sort(reverse=True)
+    assert len(rows) > 250, len(rows)
+    print(f"gradient error vs fp64, split / fp32 policy, {len(rows)} tensors: worst ratio {rows[0][0]:.2f} ({rows[0][3]}: {rows[0][1]:.2e} vs {rows[0][2]:.2e}), "
+          f"median ratio {rows[len(rows) // 2][0]:.2f}")
 
 
 def test_config2_batch16_properties(cuda):
