@@ -24,7 +24,9 @@ __version__ = "0.1.0"
 #   * importing this package changes nothing in the environment;
 #   * graph replay no longer DEPENDS on the switch: `graph_replay_is_safe()` is True unless the memset nodes were switched back on;
 #   * `enable_graph_replay()` still exists as the explicit, documented opt-in to DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (bench.py calls it
-#     before anything touches the GPU: that is the configuration with the longest soak behind it, profiles/r03_soak_2000steps_graph.txt).
+#     before anything touches the GPU: the configuration of round 3's 2000-step soak, profiles/r03_soak_2000steps_graph.txt; the same
+#     soak on the runtime's DEFAULT packet path after the fix: profiles/r04_soak_2000steps_graph_packets_on.txt - clean).  Nothing else
+#     in the package writes to the environment.
 #     It never overrides a value the user exported and does nothing once HIP may be up (a profiler preload, an initialised torch).
 import os as _os
 import sys as _sys

@@ -491,11 +491,8 @@ class Model(Layer):
 
     @use_graph.setter
     def use_graph(self, on: bool) -> None:
-        # Opting in to graph replay is also the opt-in to the runtime switch it needs (boosted_detr_amd.enable_graph_replay: a no-op
-        # once HIP is up - _graph_signature then refuses to capture and the steps stay eager, with one warning).
-        if on:
-            from . import enable_graph_replay
-            enable_graph_replay()
+        # (no environment write here: since round 4 the replay is sound on the runtime's default packet path - the captured chain holds
+        # kernel nodes only; boosted_detr_amd.enable_graph_replay() remains as an explicit opt-in to DEBUG_CLR_GRAPH_PACKET_CAPTURE=0)
         self.__dict__["_use_graph"] = bool(on)
 
     # -- Keras bookkeeping -----------------------------------------------------------------
