@@ -286,6 +286,14 @@ int hconv_tile(int64_t rows, int W, int C, int J, bool f16) {
     if (C % 32 || J % 64 || rows >= (1LL << 31)) return 0;
     const int bn = J % 128 == 0 ? 128 : 64;
     const int64_t cus = num_cus();
+    {   // A/B switch (tools/hconv_tile_ab.py, profiles/r04_hconv_tile_ab.json): BDETR_HCONV_TILE=256128 | 128128 | 256064 forces a tile where it fits
+        static int forced = -1;
+        if (forced < 0) { const char* e = getenv("BDETR_HCONV_TILE"); forced = e ? atoi(e) : 0; }
+        if (forced) {
+            const int fbm = forced / 1000, fbn = forced % 1000;
+            if ((fbn == 128 || fbn == 64) && (fbm == 128 || fbm == 256) && !(fbm == 128 && fbn == 64) && J % fbn == 0 && fbm + 2 * W + 2 <= halo_cap(fbn)) return forced;
+        }
+    }
     // the bigger tile while it still gives most CUs a workgroup (one 8-wave workgroup per CU)
     int bm = cdiv64(rows, 256) * cdiv64(J, bn) * 10 >= cus * 7 ? 256 : 128;
     if (bm + 2 * W + 2 > halo_cap(bn)) bm = 128;
