@@ -484,7 +484,8 @@ def main():
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": traffic if is_config2(args) else None,
                     "traffic_provenance": traffic_src if is_config2(args) else None,
-                    "kernel": "igemm_kernel + sgemm_kernel (MFMA implicit-GEMM family: conv fwd/bwd-data/bwd-weight, dense; algorithmic FLOPs = 2*I*J*R)",
+                    "kernel": "igemm_kernel + sgemm_kernel + hconv_kernel + rowchain_fwd/bwd_kernel (MFMA conv / GEMM family: conv fwd / bwd-data / bwd-weight, Dense, the fused "
+                              "transformer row chains; algorithmic FLOPs = 2*I*J*R)",
                     "peak_note": "FLOP-weighted harmonic mean of the per-arithmetic peaks in by_arithmetic (fp32 MFMA 157.3; split = 2500/3)",
                     "by_arithmetic": by_arith,
                     "by_class": by_class,

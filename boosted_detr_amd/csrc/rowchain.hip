@@ -21,7 +21,7 @@
 // matrix, pre-packed in fragment order ([tile][k-step][hi | lo][lane] x 16 bytes: one fully coalesced 1-KiB load per fragment),
 // prefetched four k-steps ahead across stage boundaries (weights do not depend on data).  What bounds a stage is the 256 KB of
 // weights each workgroup streams from L2 (~70 GB/s per CU): ~3.7 us per stage, not the 96 MFMAs per wave.
-#include "common.h"
+#include "gemm_common.h"
 #include "p16.h"
 
 namespace {
@@ -567,7 +567,11 @@ extern "C" int bdetr_rowchain_fwd(const bdetr_rowchain_fwd_desc* d, void* stream
     a.g1 = d->g1; a.b1 = d->b1; a.g2 = d->g2; a.b2 = d->b2;
     a.pre1 = d->pre1; a.x1 = d->x1; a.mean1 = d->mean1; a.rstd1 = d->rstd1; a.h = d->h; a.pre2 = d->pre2; a.x2 = d->x2; a.mean2 = d->mean2; a.rstd2 = d->rstd2;
     a.seed1 = d->seed1; a.seed2 = d->seed2; a.seed_base = d->seed_base;
+    // live profiling (bench.py's roofline leg): the chain's GEMM stages count as one launch of nstages x 2 M 256^2 algorithmic FLOPs
+    const bool prof = bdgemm::g_prof_on;
+    if (prof) bdgemm::prof_begin((hipStream_t)stream, 2.0 * (double)d->M * RD * RD * d->nstages, (int)d->M, RD, RD * d->nstages, 1, RBM, RD * 10 + 7, bdgemm::AR_FP16X3 * 10000 + 6000);
     hipLaunchKernelGGL(rowchain_fwd_kernel, dim3((unsigned)cdiv64(d->M, RBM)), dim3(RNT), 0, (hipStream_t)stream, a);
+    if (prof) bdgemm::prof_end((hipStream_t)stream);
     return bdetr_launch_status("rowchain_fwd");
 }
 
@@ -581,7 +585,10 @@ extern "C" int bdetr_rowchain_bwd(const bdetr_rowchain_bwd_desc* d, void* stream
     for (int k = 0; k < 3; ++k) a.wt[k] = d->wt[k];
     a.G2 = d->G2; a.G1 = d->G1; a.G0 = d->G0; a.dresid = d->dresid; a.dctx = d->dctx; a.partials = d->partials;
     a.seed1 = d->seed1; a.seed2 = d->seed2; a.seed_base = d->seed_base;
+    const bool prof = bdgemm::g_prof_on;
+    if (prof) bdgemm::prof_begin((hipStream_t)stream, 2.0 * (double)d->M * RD * RD * d->nstages, (int)d->M, RD, RD * d->nstages, 1, RBM, RD * 10 + 7, bdgemm::AR_BF16X3 * 10000 + 6000);
     hipLaunchKernelGGL(rowchain_bwd_kernel, dim3((unsigned)cdiv64(d->M, RBM)), dim3(RNT), 0, (hipStream_t)stream, a);
+    if (prof) bdgemm::prof_end((hipStream_t)stream);
     return bdetr_launch_status("rowchain_bwd");
 }
 
