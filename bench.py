@@ -160,7 +160,7 @@ def step_hbm(ms_per_step):
 ENV_REFUSED = ("BDETR_SGEMM_DBG", "BDETR_GRAPH_UNSAFE")
 ENV_RECORDED = ("BDETR_STILE", "BDETR_TILE", "BDETR_P16", "BDETR_BN_FUSE", "BDETR_LAZY_SKIP", "BDETR_WGRAD_WANT", "BDETR_WGRAD_MINSTAGES",
                 "BDETR_GEMM_PRECISION", "BDETR_SIDE_STREAM", "BDETR_SIDE_PRIORITY", "BDETR_GRAPH", "BDETR_DP_OVERLAP", "BDETR_DP_FORCE", "BDETR_LIB",
-                "BDETR_CXXFLAGS", "BDETR_FORCE_DEVICE", "BDETR_DIST_BACKEND", "BDETR_CPU_THREADS", "BDETR_HCONV", "BDETR_ATTN_SPLIT", "BDETR_WGRAD_XF16", "BDETR_BF16_3X3", "BDETR_WGRAD_1X1_TILE", "BDETR_GRAPH_SEG", "BDETR_GRAPH_SIDE", "BDETR_DETERMINISTIC", "BDETR_ROWCHAIN", "BDETR_ZERO_MEMSET")
+                "BDETR_CXXFLAGS", "BDETR_FORCE_DEVICE", "BDETR_DIST_BACKEND", "BDETR_CPU_THREADS", "BDETR_HCONV", "BDETR_ATTN_SPLIT", "BDETR_WGRAD_XF16", "BDETR_BF16_3X3", "BDETR_WGRAD_1X1_TILE", "BDETR_GRAPH_SEG", "BDETR_GRAPH_SIDE", "BDETR_DETERMINISTIC", "BDETR_ROWCHAIN", "BDETR_ZERO_MEMSET", "BDETR_DP_GRAPH", "BDETR_HWGRAD", "BDETR_BN_FUSE2", "BDETR_HCONV_TILE")
 
 
 def env_overrides() -> dict:
@@ -351,7 +351,13 @@ def main():
     if distributed:
         model.distribute()
     want_graph = not args.no_graph and os.environ.get("BDETR_GRAPH", "1") != "0"
-    model.use_graph = want_graph and graph_ok            # N > 1 replays too: the bucket all-reduces are captured into the chain (Model._graph_step)
+    # N > 1 replays too: the bucket all-reduces are captured into the chain (Model._graph_step; rehearsed over a one-rank RCCL
+    # communicator - tests/test_dp_gpu.py - no multi-GPU node was available to this build).  BDETR_DP_GRAPH=0 keeps the eagerly enqueued
+    # data-parallel step (collectives issued per bucket from the backward pass on a communication stream), and a capture that raises
+    # falls back to it on every rank (the ranks agree through a MIN all-reduce).
+    if distributed and os.environ.get("BDETR_DP_GRAPH", "1") == "0":
+        want_graph = False
+    model.use_graph = want_graph and graph_ok
     graph_refused = want_graph and not graph_ok
 
     def note(msg):
@@ -359,6 +365,7 @@ def main():
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
     masks = [None]
+    graph_fallback = None
 
     def run_step(b):
         """One step of the workload: the unmodified train_step (+ the mask head's forward on that step's features with --panoptic)."""
@@ -369,9 +376,23 @@ def main():
     if model.use_graph:
         # build-by-first-call, allocator warm-up and the capture itself (third step on a signature) are set-up, like the build:
         # they happen before the W warm-up steps, so that warm-up and timed steps are all replays whatever W is
+        capture_failed = None
         for i in range(4):
             tw = time.perf_counter()
-            run_step(batch)
+            try:
+                run_step(batch)
+            except Exception as exc:                       # (a failed capture leaves the stream usable: SegmentedCapture.abort)
+                if not distributed:
+                    raise
+                capture_failed = repr(exc)[:300]
+            ok = torch.tensor([0 if capture_failed else 1], dtype=torch.int32, device="cuda")
+            if dist is not None:
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                note(f"graph capture of the data-parallel step failed on some rank ({capture_failed}): eagerly enqueued steps instead")
+                model.use_graph, model._graphs, model._graph_warm = False, {}, {}
+                graph_fallback = capture_failed or "another rank"
+                break
             torch.cuda.synchronize()
             note(f"set-up step {i} ({'captured' if model._graphs else 'eager'}): {(time.perf_counter() - tw) * 1e3:.1f} ms")
             if model._graphs:
@@ -605,7 +626,7 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": dtype_note(model), "arithmetic": arithmetic_note(model), "data": "synthetic",
             "config": {"workload": workload_name(args), "per_gpu_batch": args.batch, "global_batch": global_batch,
-                       "parallelism": f"dp{world}", "step_launch": step_launch,
+                       "parallelism": f"dp{world}", "step_launch": step_launch, "graph_capture_fallback": graph_fallback,
                        "runtime_switches": {"DEBUG_CLR_GRAPH_PACKET_CAPTURE": os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE"),
                                             "packet_capture_off_in_force": boosted_detr_amd.packet_capture_off(),
                                             "zero_fill": "hipMemset nodes" if os.environ.get("BDETR_ZERO_MEMSET") == "1" else "library kernel (no memset nodes in the captured step)"}, "gflop_per_image_algorithmic": gflop_img,
