@@ -377,7 +377,7 @@ def main():
         # build-by-first-call, allocator warm-up and the capture itself (third step on a signature) are set-up, like the build:
         # they happen before the W warm-up steps, so that warm-up and timed steps are all replays whatever W is
         capture_failed = None
-        for i in range(4):
+        for i in range(7 if distributed else 4):           # (data-parallel: two more eager steps first - replica broadcast, bucket-table calibration)
             tw = time.perf_counter()
             try:
                 run_step(batch)
