@@ -133,6 +133,8 @@ SIGNATURES = {
     "bdetr_bn_bwd": (I, [P, P, P, P, P, P, P, I, I, P, P, P, P, P, L, I, P]),
     "bdetr_maxpool3x3s2_fwd": (I, [P, P, I, I, I, I, I, I, P]),
     "bdetr_maxpool3x3s2_bwd": (I, [P, P, P, P, I, I, I, I, I, I, P]),
+    "bdetr_stem_pool_fwd": (I, [P, P, P, P, P, I, I, I, I, P, P, P, P, P]),
+    "bdetr_stem_pool_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, P, P, P, P, P]),
     "bdetr_attention_head_dim": (I, []),
     "bdetr_attention_fwd": (I, [P, P, P, P, P, I, I, I, I, F, P]),
     "bdetr_attention_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, P]),

@@ -77,8 +77,8 @@ class ResNet(Layer):
 
     def call(self, inputs, training=False):
         x = inputs[0]                                    # [B,H,W,4] prepared image
-        x = self.stem([x], training=training, relu=True, x_needs_grad=False)
-        x = ops.maxpool(x)
+        st = self.stem
+        x = ops.conv_bn_relu_maxpool(x, st.kernel, st.bias, st.bn, st.stride, st.pad, training, training and st.trainable)
         # Inside a bottleneck the 1x1 -> 3x3 -> 1x1 links are consumed by convolutions only: on the pre-split operand
         # path (ops.conv_bn, 'split' policy) they exist as 16-bit pairs and never as fp32 tensors.  Block outputs are also
         # the next block's shortcut (read back from the f16 pair) and their own ReLU-mask source in the backward pass (the

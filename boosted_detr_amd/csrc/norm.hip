@@ -264,6 +264,119 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     }
 }
 
+// ---- the ResNet stem's tail: BatchNorm -> ReLU -> ZeroPadding2D(1) -> MaxPool 3x3 / 2 in one pass each way -------------------------
+// (keras ResNet50 conv1_bn / conv1_relu / pool1_pad / pool1_pool, reached from the reference's backbone.py:79-80.)  The 64-channel
+// 320x320 tensor between conv1 and the pool is the largest activation of the network (420 MB at 32 images); unfused it is written by
+// bn_apply, read by the pool, and in the backward pass written by the pool's backward and read twice by BatchNorm's - here it exists only
+// as the RAW convolution output y: the forward pass normalises inside the pooling window and writes the pooled tensor as the f16 pair
+// its two consumers read plus one byte per element naming the window tap that held the maximum; the backward pass rebuilds the
+// gradient of the normalised tensor from those bytes on the fly, in BatchNorm's reduction pass and again in its apply pass.
+// A tie goes to the first tap in (row, column) order.  Ties between positive values need bit-equal fp32 numbers; ties at zero get
+// no gradient either way (the ReLU mask).
+struct StemGeom { int N, H, W, C, PH, PW; };
+
+__global__ __launch_bounds__(256) void stem_pool_fwd_kernel(const float* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta, StemGeom s,
+                                                            float* __restrict__ out32, void* __restrict__ out_f16, unsigned* __restrict__ tap,
+                                                            int* __restrict__ overflow_flag) {
+    const int c4n = s.C / 4;
+    const int64_t n4 = (int64_t)s.N * s.PH * s.PW * c4n;      // even, and the stride is even: the two lanes of an f16 pair group run together
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n); unsigned t = (unsigned)(i / c4n);
+        const int pw = (int)(t % (unsigned)s.PW); t /= (unsigned)s.PW; const int ph = (int)(t % (unsigned)s.PH); const int n = (int)(t / (unsigned)s.PH);
+        const int c = c4 * 4;
+        const f32x4 m = *reinterpret_cast<const f32x4*>(mean + c), rs = *reinterpret_cast<const f32x4*>(rstd + c);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c), b = *reinterpret_cast<const f32x4*>(beta + c);
+        f32x4 v[9];
+        bool in[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {                        // all nine loads in flight before the first compare
+            const int ih = ph * 2 - 1 + k / 3, iw = pw * 2 - 1 + k % 3;
+            in[k] = (unsigned)ih < (unsigned)s.H && (unsigned)iw < (unsigned)s.W;
+            v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (in[k]) v[k] = reinterpret_cast<const f32x4*>(y)[(((int64_t)n * s.H + ih) * s.W + iw) * c4n + c4];
+        }
+        // (the padding ring holds zeros and every window has a real tap, whose value is >= 0 after the ReLU: skipping the ring's
+        // taps gives the same maximum as comparing against their zeros)
+        f32x4 mx = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        unsigned arg = 0;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            if (!in[k]) continue;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = fmaxf(bn_affine(v[k][e], m[e], rs[e], g[e], b[e]), 0.f);
+                if (a > mx[e]) { mx[e] = a; arg = (arg & ~(0xFFu << (8 * e))) | ((unsigned)k << (8 * e)); }
+            }
+        }
+        tap[i] = arg;
+        if (out32 != nullptr) reinterpret_cast<f32x4*>(out32)[i] = mx;
+        if (out_f16 != nullptr) {
+            p16_store4<true>(out_f16, i, mx[0], mx[1], mx[2], mx[3]);
+            if (overflow_flag != nullptr) {
+                const float top = fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3]));
+                if (!(top < P16_F16_LIMIT)) *overflow_flag = 1;       // (-inf survives only where every tap was NaN: caught here too)
+            }
+        }
+    }
+}
+
+// gradient of the NORMALISED, rectified tensor at input pixel `px` (flat n*H*W + ih*W + iw), channels c..c+3: the pooled gradient of
+// every window whose recorded tap is this pixel, masked by the ReLU (recomputed from y with the forward's bn_affine).  Also returns xhat.
+__device__ __forceinline__ f32x4 stem_pixel_grad(const float* __restrict__ dpool, const unsigned* __restrict__ tap, const StemGeom& s, unsigned px, int c,
+                                                 const f32x4 yv, const f32x4 m, const f32x4 rs, const f32x4 gm, const f32x4 bt, f32x4& xhat) {
+    const int c4n = s.C / 4, c4 = c / 4;
+    const int iw = (int)(px % (unsigned)s.W); const unsigned t = px / (unsigned)s.W;
+    const int ih = (int)(t % (unsigned)s.H), n = (int)(t / (unsigned)s.H);
+    // windows ph with 2 ph - 1 <= ih <= 2 ph + 1: ih / 2 and, for odd ih, (ih + 1) / 2
+    const int ph0 = ih >> 1, pw0 = iw >> 1;
+    const int nph = 1 + ((ih & 1) & (int)(ph0 + 1 < s.PH)), npw = 1 + ((iw & 1) & (int)(pw0 + 1 < s.PW));
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < nph; ++a)
+        for (int b = 0; b < npw; ++b) {
+            const int ph = ph0 + a, pw = pw0 + b;
+            const int64_t o = (((int64_t)n * s.PH + ph) * s.PW + pw) * c4n + c4;
+            const unsigned mine = (unsigned)((ih - (ph * 2 - 1)) * 3 + (iw - (pw * 2 - 1)));
+            const unsigned word = tap[o];
+            const f32x4 dv = reinterpret_cast<const f32x4*>(dpool)[o];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (((word >> (8 * e)) & 0xFFu) == mine) g[e] += dv[e];
+        }
+    xhat = (yv - m) * rs;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) if (!(bn_affine(yv[e], m[e], rs[e], gm[e], bt[e]) > 0.f)) g[e] = 0.f;
+    return g;
+}
+
+struct StemBwdFn {   // a = g, b = g * xhat  (colreduce2_kernel functor; `r` is the flat input pixel)
+    const float* dpool; const unsigned* tap; const float* y; const float* mean; const float* rstd; const float* gamma; const float* beta; StemGeom s;
+    __device__ __forceinline__ void operator()(int64_t r, int c, f32x4& a, f32x4& b) const {
+        const f32x4 yv = *reinterpret_cast<const f32x4*>(y + r * s.C + c);
+        const f32x4 m = *reinterpret_cast<const f32x4*>(mean + c), rs = *reinterpret_cast<const f32x4*>(rstd + c);
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c), bt = *reinterpret_cast<const f32x4*>(beta + c);
+        f32x4 xh;
+        a = stem_pixel_grad(dpool, tap, s, (unsigned)r, c, yv, m, rs, gm, bt, xh);
+        b = a * xh;
+    }
+};
+
+__global__ __launch_bounds__(256) void stem_bwd_apply_kernel(const float* __restrict__ dpool, const unsigned* __restrict__ tap, const float* __restrict__ y,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                                             StemGeom s, float* __restrict__ dy, int64_t n4, float inv_rows) {
+    const int c4n = s.C / 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4n) * 4;
+        const f32x4 yv = reinterpret_cast<const f32x4*>(y)[i];
+        const f32x4 m = *reinterpret_cast<const f32x4*>(mean + c), rs = *reinterpret_cast<const f32x4*>(rstd + c);
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c), bt = *reinterpret_cast<const f32x4*>(beta + c);
+        const f32x4 dg = *reinterpret_cast<const f32x4*>(dgamma + c), db = *reinterpret_cast<const f32x4*>(dbeta + c);
+        f32x4 xh;
+        const f32x4 g = stem_pixel_grad(dpool, tap, s, (unsigned)(i / c4n), c, yv, m, rs, gm, bt, xh);
+        reinterpret_cast<f32x4*>(dy)[i] = (g - db * inv_rows - xh * (dg * inv_rows)) * (rs * gm);      // bn_bwd_apply_kernel's expression
+    }
+}
+
 // ---- P16 producers (sgemm.hip operand layout): the same maps as bn_apply / bn_bwd_apply, 8 channels per thread,
 // writing the f16 pair (forward operand of the consumer conv), the bf16 pair (its weight-gradient operand) and / or
 // the fp32 tensor.  The fp32 arithmetic is identical to the kernels above (bn_affine), so a ReLU mask recomputed in
@@ -640,6 +753,39 @@ extern "C" int bdetr_bn_bwd(const float* dout, const float* out, const float* x,
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n4, 256, 2)), dim3(256), 0, st, dout, out, x, mean, rstd, gamma, beta, dgamma, dbeta,
                        relu, frozen, dx, dresidual, n4, C / 4, 1.0f / (float)rows);
     return bdetr_launch_status("bn_bwd");
+}
+
+extern "C" int bdetr_stem_pool_fwd(const float* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                   int N, int H, int W, int C, float* out32, void* out_f16, uint8_t* tap, int* overflow_flag, void* stream) {
+    BDETR_CHECK_ARG(y && mean && rstd && gamma && beta && tap && (out32 || out_f16) && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0,
+                    "bdetr_stem_pool_fwd: bad arguments (C %% 8 == 0 required)");
+    BDETR_CHECK_ARG((int64_t)N * H * W < (int64_t)1 << 31, "bdetr_stem_pool_fwd: more than 2^31 pixels");
+    const StemGeom s{N, H, W, C, (H + 2 - 3) / 2 + 1, (W + 2 - 3) / 2 + 1};
+    const int64_t n4 = (int64_t)N * s.PH * s.PW * (C / 4);
+    hipLaunchKernelGGL(stem_pool_fwd_kernel, dim3(ew_grid(n4, 256, 1)), dim3(256), 0, (hipStream_t)stream, y, mean, rstd, gamma, beta, s, out32, out_f16,
+                       reinterpret_cast<unsigned*>(tap), overflow_flag);
+    return bdetr_launch_status("stem_pool_fwd");
+}
+
+extern "C" int bdetr_stem_pool_bwd(const float* dpool, const uint8_t* tap, const float* y, const float* mean, const float* rstd, const float* gamma,
+                                   const float* beta, int N, int H, int W, int C, float* dy, float* dgamma, float* dbeta, float* ws, void* stream) {
+    BDETR_CHECK_ARG(dpool && tap && y && mean && rstd && gamma && beta && dy && dgamma && dbeta && ws && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0,
+                    "bdetr_stem_pool_bwd: bad arguments (C %% 8 == 0 required)");
+    BDETR_CHECK_ARG((int64_t)N * H * W < (int64_t)1 << 31, "bdetr_stem_pool_bwd: more than 2^31 pixels");
+    hipStream_t st = (hipStream_t)stream;
+    const StemGeom s{N, H, W, C, (H + 2 - 3) / 2 + 1, (W + 2 - 3) / 2 + 1};
+    const int64_t rows = (int64_t)N * H * W;
+    ColGeom g = col_geom(C);
+    int64_t rpc = chunk_rows_for(rows, chunks_for_width(g.gx), 64);   // <= bdetr_bn_bwd_chunks(rows), which sizes ws
+    int nch = (int)cdiv64(rows, rpc);
+    float* pa = ws; float* pb = ws + (int64_t)nch * C;
+    StemBwdFn f{dpool, reinterpret_cast<const unsigned*>(tap), y, mean, rstd, gamma, beta, s};
+    hipLaunchKernelGGL((colreduce2_kernel<StemBwdFn>), dim3(g.gx, nch), dim3(256), 0, st, f, rows, C, g.tx, rpc, pa, pb);
+    hipLaunchKernelGGL(sum_partials2_kernel, dim3((C + 7) / 8), dim3(256), 0, st, pa, pb, nch, C, dbeta, dgamma);
+    const int64_t n4 = rows * C / 4;
+    hipLaunchKernelGGL(stem_bwd_apply_kernel, dim3(ew_grid(n4, 256, 2)), dim3(256), 0, st, dpool, reinterpret_cast<const unsigned*>(tap), y, mean, rstd, gamma, beta,
+                       dgamma, dbeta, s, dy, n4, 1.0f / (float)rows);
+    return bdetr_launch_status("stem_pool_bwd");
 }
 
 extern "C" int bdetr_bn_apply_p16(const float* x, const float* mean, const float* rstd, const float* gamma,

@@ -695,6 +695,35 @@ def maxpool_bwd(x, y, dy):
     return dx
 
 
+def stem_pool_fwd(y, mean, rstd, gamma, beta, want_fp32=False):
+    """BatchNorm -> ReLU -> pad 1 -> MaxPool 3x3/2 of the raw stem convolution output y [N,H,W,C]: (pooled fp32 | None, pooled f16
+    pair, tap bytes) - csrc/norm.hip stem_pool_fwd_kernel."""
+    _chk(y, mean, rstd, gamma, beta)
+    N, H, W, Cc = y.shape
+    PH, PW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    o32 = empty(N, PH, PW, Cc, like=y) if want_fp32 else None
+    of = empty(N, PH, PW, Cc, like=y)
+    tap = torch.empty((N, PH, PW, Cc), dtype=torch.uint8, device=y.device)
+    check(_lib.lib().bdetr_stem_pool_fwd(_p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), N, H, W, Cc, _p(o32), _p(of), _p(tap),
+                                         _p(overflow_flag()), _stream()), "stem_pool_fwd")
+    return o32, of, tap
+
+
+def stem_pool_bwd(dpool, tap, y, mean, rstd, gamma, beta, dgamma=None, dbeta=None):
+    """The backward of stem_pool_fwd + BatchNorm (batch statistics): (dy [N,H,W,C], dgamma, dbeta)."""
+    _chk(dpool, y, mean, rstd, gamma, beta, dgamma, dbeta)
+    assert tap.is_cuda and tap.is_contiguous() and tap.dtype == torch.uint8 and tuple(tap.shape) == tuple(dpool.shape)
+    L = _lib.lib()
+    N, H, W, Cc = y.shape
+    dy = torch.empty_like(y)
+    dgamma = empty(Cc, like=y) if dgamma is None else dgamma
+    dbeta = empty(Cc, like=y) if dbeta is None else dbeta
+    ws = empty(2 * Cc * L.bdetr_bn_bwd_chunks(N * H * W), like=y)
+    check(L.bdetr_stem_pool_bwd(_p(dpool), _p(tap), _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), N, H, W, Cc, _p(dy), _p(dgamma), _p(dbeta),
+                                _p(ws), _stream()), "stem_pool_bwd")
+    return dy, dgamma, dbeta
+
+
 def attention_fwd(q, k, v, heads, scale):
     """q [B,nq,h*32], k/v [B,nk,h*32] -> o [B,h,nq,32], lse [B,h,nq] (fused; scores never hit HBM)."""
     _chk(q, k, v)

@@ -468,6 +468,51 @@ def maxpool(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
+STEM_FUSE = os.environ.get("BDETR_STEM_FUSE", "1") != "0"
+
+
+def conv_bn_relu_maxpool(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int, pad: int, training: bool,
+                         bn_batch_stats: bool) -> torch.Tensor:
+    """The ResNet stem: Conv2D(+bias) -> BatchNormalization -> ReLU -> ZeroPadding2D(1) -> MaxPool 3x3/2; the input image needs no
+    gradient.  Training with batch statistics under the 'split' policy, the tail runs fused (csrc/norm.hip stem_*): the pooled tensor is
+    written once, as the f16 pair its consumers read (the returned handle IS that copy, like a link inside a bottleneck), and the
+    normalised full-resolution tensor and its gradient are never materialised.  Otherwise: conv_bn + maxpool."""
+    N, H, W, Cin = x.shape
+    Kout, R, S, _ = w.value.shape
+    if not (STEM_FUSE and training and bn_batch_stats and _p16_active() and Kout % 8 == 0):
+        return maxpool(conv_bn(x, w, b, bn, stride, pad, True, training=training, bn_batch_stats=bn_batch_stats, x_needs_grad=False))
+    g = K.ConvGeom(N, H, W, Cin, Kout, R, S, stride, pad)
+    x32 = as_fp32(x)
+    y, parts = K.conv2d_fwd(x32, w.value, b.value, g, K.ACT_NONE, want_stats=True)
+    if parts is None or parts[0] is None:
+        parts = K.colstats(_2d(y))
+    mean, rstd = K.bn_stats(g.M, Kout, parts, bn.eps, bn.momentum, True, bn.moving_mean.value, bn.moving_var.value, like=y)
+    _, out, tap = K.stem_pool_fwd(y, mean, rstd, bn.gamma.value, bn.beta.value)
+    out._p16f, out._p16b, out._p16_only = out, None, True
+
+    def backward(g_out):
+        sg, sb = GradSink(bn.gamma), GradSink(bn.beta)
+        dy, _, _ = K.stem_pool_bwd(materialise(g_out).contiguous(), tap, y, mean, rstd, bn.gamma.value, bn.beta.value, dgamma=sg.buf, dbeta=sb.buf)
+        sg.commit()
+        sb.commit()
+        if w.needs_grad or b.needs_grad:
+            def param_grads(dy=dy):
+                if w.needs_grad:
+                    s = GradSink(w)
+                    K.conv2d_bwd_weight(x32, dy, g, dw=s.buf, prezeroed=s.mode == "direct")
+                    s.commit()
+                if b.needs_grad:
+                    s = GradSink(b)             # exactly zero in front of a batch-statistics BatchNorm (see conv_bn)
+                    if s.mode != "direct":
+                        K.zero_(s.buf)
+                    s.commit()
+            side_task(param_grads, x32, dy)
+        return (None,)
+
+    _rec([out], [x], backward)
+    return out
+
+
 # ----------------------------------------------------------------------------------------
 # dense / elementwise
 # ----------------------------------------------------------------------------------------

@@ -345,6 +345,17 @@ int bdetr_maxpool3x3s2_fwd(const float* x, float* y, int N, int H, int W, int C,
 int bdetr_maxpool3x3s2_bwd(const float* x, const float* y, const float* dy, float* dx,
                            int N, int H, int W, int C, int OH, int OW, void* stream);
 
+/* The ResNet stem's tail in one pass each way (training, batch statistics): BatchNormalization -> ReLU -> ZeroPadding2D(1) ->
+ * MaxPool 3x3/2 over the RAW conv1 output y [N,H,W,C] (keras ResNet50 conv1_bn .. pool1_pool, reached from backbone.py:79-80).
+ * fwd: pooled tensor [N,PH,PW,C] (PH = (H-1)/2+1) as fp32 (out32) and / or as the f16 pair of the P16 layout (out_f16), plus
+ *      tap [N,PH,PW,C] bytes: which of the window's 9 taps (row-major) held the maximum - the first one on a tie.
+ * bwd: dpool [N,PH,PW,C] -> dy [N,H,W,C] (gradient of the raw conv output), dgamma, dbeta; the normalised full-resolution tensor
+ *      and its gradient are never materialised.  ws: 2*C*bdetr_bn_bwd_chunks(N*H*W) floats.  C % 8 == 0, N*H*W < 2^31. */
+int bdetr_stem_pool_fwd(const float* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                        int N, int H, int W, int C, float* out32, void* out_f16, uint8_t* tap, int* overflow_flag, void* stream);
+int bdetr_stem_pool_bwd(const float* dpool, const uint8_t* tap, const float* y, const float* mean, const float* rstd, const float* gamma,
+                        const float* beta, int N, int H, int W, int C, float* dy, float* dgamma, float* dbeta, float* ws, void* stream);
+
 /* ------------------------------------------------------------------------
  * K7  attention softmax (transformers.py:88-94): p = softmax(scale*s) row-wise, in place ok.
  *     bwd: ds = scale * p * (dp - sum_k dp*p)
