@@ -467,6 +467,7 @@ class Model(Layer):
         # forward_backward run under the library default ('mixed': exact fp32 forward).  The environment
         # variable BDETR_GEMM_PRECISION, when set, wins (None = leave the library's mode alone).
         self.train_gemm_precision = None if os.environ.get("BDETR_GEMM_PRECISION") else "split"
+        self.train_grad_precision = None      # None: the backward pass runs under train_gemm_precision too
         self.validate_matching = False      # fit() turns this on: it synchronises every step anyway (host logging)
         # Range guard of the 'split' policy: the f16 pairs of its forward products hold |x| < 65504, the reference's
         # fp32 does not overflow there.  Producers raise a device flag instead of feeding NaN downstream; while it is
@@ -568,12 +569,15 @@ class Model(Layer):
             with K.gemm_precision(self.train_gemm_precision):
                 with recording(tape):
                     y_pred = self(data, training=True)
-                tape.backward({id(t): t for t in self._loss_roots})     # parameter gradients land in Variable.grad (ops.GradSink)
-                from . import engine as _engine
-                if _engine._CAPTURE[0] is not None:
-                    _engine._CAPTURE[0].cut()        # segmented capture: close the backward's last segment (its side tasks need this step's sinks)
-                elif _engine._DEBUG_LOG[0] is not None:
-                    _engine._debug_cut(None)         # (diagnostic twin of that cut in an eager step)
+                # train_grad_precision: the backward pass under its own policy ('fp32' after a 'split' forward = every product of the step
+                # at 2^-22 or better; the backward closures pick their kernels by the policy in force when they run: ops.conv_bn)
+                with K.gemm_precision(self.train_grad_precision):
+                    tape.backward({id(t): t for t in self._loss_roots})     # parameter gradients land in Variable.grad (ops.GradSink)
+                    from . import engine as _engine
+                    if _engine._CAPTURE[0] is not None:
+                        _engine._CAPTURE[0].cut()        # segmented capture: close the backward's last segment (its side tasks need this step's sinks)
+                    elif _engine._DEBUG_LOG[0] is not None:
+                        _engine._debug_cut(None)         # (diagnostic twin of that cut in an eager step)
             self._kept_tape = tape if keep_tape else None
         finally:
             K.set_launch_stream(prev)
@@ -633,7 +637,7 @@ class Model(Layer):
             return None
         if not all(isinstance(v, torch.Tensor) and v.is_cuda for v in data.values()):
             return None
-        return tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(data.items())) + (self.train_gemm_precision,) + self._graph_env()
+        return tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(data.items())) + (self.train_gemm_precision, self.train_grad_precision) + self._graph_env()
 
     def _graph_env(self) -> tuple:
         """Everything a captured step bakes in besides its input shapes: the optimizer object and the variables its flat

@@ -81,8 +81,12 @@ def test_config2_batch2_matches_oracle(cuda):
         assert e_s <= 2.0 * e_f + 1e-4, (name, e_s, e_f)
     rows.sort(reverse=True)
     assert len(rows) > 250, len(rows)
+    over = [r for r in rows if r[0] > 2.0]
     print(f"gradient error vs fp64, split / fp32 policy, {len(rows)} tensors: worst ratio {rows[0][0]:.2f} ({rows[0][3]}: {rows[0][1]:.2e} vs {rows[0][2]:.2e}), "
-          f"median ratio {rows[len(rows) // 2][0]:.2f}")
+          f"median ratio {rows[len(rows) // 2][0]:.2f}; {len(over)} tensors above 2x, their largest split error {max([r[1] for r in over], default=0.0):.2e}; "
+          f"largest error overall: split {max(r[1] for r in rows):.2e}, fp32 {max(r[2] for r in rows):.2e}")
+    # (measured, round 4: the tensors above 2x are all at errors below 1e-5 of their norm - the bound holds with a floor of 2e-5)
+    assert all(r[1] <= 2.0 * r[2] + 2e-5 for r in rows), [r for r in rows if r[1] > 2.0 * r[2] + 2e-5][:3]
 
 
 def test_config2_batch16_properties(cuda):

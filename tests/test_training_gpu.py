@@ -532,3 +532,43 @@ def test_replayed_step_is_bit_identical_with_the_runtime_packet_path_on(cuda):
     for kind in ("L", "F", "A", "S"):
         assert out[kind]["n"][0] == out[kind]["n"][1] > 0, (kind, out[kind])
         assert out[kind]["first_difference"] is None and out[kind]["first_nonfinite_or_flag_in_graph_run"] is None, (kind, out[kind])
+
+
+def test_gradient_policy_of_its_own_runs_the_backward_under_it(cuda, deterministic):
+    """Model.train_grad_precision = 'fp32' after the 'split' forward (bench.py's value_fp32_grade leg: no product of the step below
+    2^-22): the gradients ARE the ones replay_backward('fp32') computes from the same saved forward - bit for bit in deterministic
+    mode - and differ from the all-'split' step's; a captured step under that policy equals the eager one."""
+    from boosted_detr_amd.engine import to_device
+    from boosted_detr_amd.training import SGD
+    from oracle import detr_oracle as O
+    cfg, host = small_batch()
+    batch = {"image": to_device(host["image"]), "category": to_device(host["category"], torch.int32), "attribute": to_device(host["attribute"], torch.int32),
+             "bbox": to_device(host["bbox"]), "num_objects": to_device(host["num_objects"], torch.int32)}
+    m = small_model(dropout=0.1)
+    m.compile(optimizer=SGD(1e-3, momentum=.9, nesterov=True, clipnorm=.1))
+    m.forward_backward(batch)
+    m.set_weights_dict(O.make_params(cfg, seed=1))
+    grads = lambda: {v.name: v.grad.detach().cpu().numpy().copy() for v in m.trainable_variables if v.grad is not None}
+    m.forward_backward(batch)
+    g_split = grads()
+    m.train_grad_precision = "fp32"
+    m.forward_backward(batch, keep_tape=True)
+    g_own = grads()
+    m.replay_backward("fp32")
+    g_replay = grads()
+    m._kept_tape = None
+    assert set(g_own) == set(g_replay) == set(g_split) and len(g_own) > 50
+    assert not [k for k in g_own if not np.array_equal(g_own[k], g_replay[k])]
+    assert any(not np.array_equal(g_own[k], g_split[k]) for k in g_own)
+    # the same policy through the captured step
+    runs = {}
+    for graph in (False, True):
+        mm = small_model(dropout=0.1)
+        mm.compile(optimizer=SGD(1e-3, momentum=.9, nesterov=True, clipnorm=.1))
+        mm.forward_backward(batch)
+        mm.set_weights_dict(O.make_params(cfg, seed=1))
+        mm.train_grad_precision, mm.use_graph = "fp32", graph
+        losses = [mm.logs_to_host(mm.train_step(batch))["loss"] for _ in range(5)]
+        assert (len(mm._graphs) == 1) == graph
+        runs[graph] = (losses, mm.get_weights_dict())
+    assert runs[False][0] == runs[True][0] and not _same_weights(runs[False][1], runs[True][1])
