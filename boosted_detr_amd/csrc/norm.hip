@@ -158,6 +158,91 @@ __global__ __launch_bounds__(256) void sum_partials2_kernel(const float* __restr
     if (py == 0 && c < C) { oa[c] = (float)s1[cx]; ob[c] = (float)s2[cx]; }
 }
 
+// Both reductions above in ONE launch for any number of partial rows (round 4: fold_partials2 + bn_finalize were two launches behind
+// every convolution with more than 256 epilogue rows, sum_partials2 walked up to 200 rows per thread): a block owns FOUR columns - one
+// 16-byte load per partial row and quantity - and its 256 threads are 256 row phases with four rows' loads in flight each, then a
+// fixed-order fp64 tree over the phases.  FINALIZE: the totals become mean / rstd / moving statistics (bn_finalize_kernel's tail),
+// else they are stored (oa <- sum pa, ob <- sum pb).  C % 4 == 0.
+struct BnFinalizeArgs { int64_t rows; float eps, momentum; int bessel; float* mean; float* rstd; float* mmean; float* mvar; int* guard; };
+
+template <bool FINALIZE>
+__global__ __launch_bounds__(256) void reduce_partials2_kernel(const float* __restrict__ pa, const float* __restrict__ pb, int nparts, int C,
+                                                               float* __restrict__ oa, float* __restrict__ ob, BnFinalizeArgs fin) {
+    __shared__ double sh[256][8];
+    const int t = threadIdx.x, c = blockIdx.x * 4;
+    double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+    int p = t;
+    for (; p + 3 * 256 < nparts; p += 4 * 256) {
+        f32x4 va[4], vb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            va[u] = *reinterpret_cast<const f32x4*>(pa + (int64_t)(p + 256 * u) * C + c);
+            vb[u] = *reinterpret_cast<const f32x4*>(pb + (int64_t)(p + 256 * u) * C + c);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a[e] += va[u][e]; b[e] += vb[u][e]; }
+    }
+    for (; p < nparts; p += 256) {
+        const f32x4 va = *reinterpret_cast<const f32x4*>(pa + (int64_t)p * C + c), vb = *reinterpret_cast<const f32x4*>(pb + (int64_t)p * C + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[e] += va[e]; b[e] += vb[e]; }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { sh[t][e] = a[e]; sh[t][4 + e] = b[e]; }
+    __syncthreads();
+    // tree over the phases: 256 -> 8 rows with all threads busy (thread = (row, value)), then the last 8 rows serially
+    for (int half = 128; half >= 8; half >>= 1) {
+        const int r = t >> 3, v = t & 7;
+        for (int rr = r; rr < half; rr += 32) sh[rr][v] += sh[rr + half][v];
+        __syncthreads();
+    }
+    if (t < 4) {
+        double ta = 0, tb = 0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { ta += sh[r][t]; tb += sh[r][4 + t]; }
+        if (!FINALIZE) { oa[c + t] = (float)ta; ob[c + t] = (float)tb; return; }
+        const double m = ta / (double)fin.rows;
+        double var = tb / (double)fin.rows - m * m;
+        if (var < 0) var = 0;
+        fin.mean[c + t] = (float)m;
+        fin.rstd[c + t] = (float)(1.0 / sqrt(var + (double)fin.eps));
+        bool ok = true;                          // (the guard: see bn_finalize_kernel)
+        if (fin.guard != nullptr) {
+            if (!(fabs(m) <= 3.0e38) || !(var <= 3.0e38)) *fin.guard = 1;
+            ok = *fin.guard == 0;
+        }
+        if (fin.mmean != nullptr && ok) {
+            const double vm = (fin.bessel && fin.rows > 1) ? var * ((double)fin.rows / (double)(fin.rows - 1)) : var;
+            fin.mmean[c + t] = fin.mmean[c + t] * fin.momentum + (float)m * (1.f - fin.momentum);
+            fin.mvar[c + t] = fin.mvar[c + t] * fin.momentum + (float)vm * (1.f - fin.momentum);
+        }
+    }
+}
+
+// fewest partial rows for which the one-launch reduction is used: BDETR_BN_WIDE_REDUCE=<rows>; unset or 0 = never, the default.
+// Measured (round 4, configs[1], 120 graph-replayed steps, three alternating runs each, images/s):
+//     never (fold_partials2 + bn_finalize / sum_partials2)   594.1  593.2  592.2
+//     from 257 rows (every case that needed the fold)         583.5  588.0  586.0
+//     from 1025 rows                                          587.9  588.1  586.1
+//     always                                                  585.1  584.2  584.9
+// One launch of C/4 workgroups that each walk every partial row is slower than two launches that spread the same walk over
+// 64 x C/32 workgroups: inside a replayed graph a launch costs ~1-2 us, less than the latency of the longer dependent walk.  The
+// three-kernel chain stays; this kernel is kept as the measured alternative.
+int wide_reduce_min() {
+    static const int n = [] { const char* e = getenv("BDETR_BN_WIDE_REDUCE"); int v = e ? atoi(e) : 0; return v <= 0 ? 0x7fffffff : v; }();
+    return n;
+}
+
+// oa <- column sums of pa, ob <- of pb
+void sum_partials2(const float* pa, const float* pb, int nparts, int C, float* oa, float* ob, hipStream_t st) {
+    if (nparts >= wide_reduce_min() && C % 4 == 0 && (reinterpret_cast<uintptr_t>(pa) | reinterpret_cast<uintptr_t>(pb)) % 16 == 0)
+        hipLaunchKernelGGL(reduce_partials2_kernel<false>, dim3(C / 4), dim3(256), 0, st, pa, pb, nparts, C, oa, ob, BnFinalizeArgs{});
+    else
+        hipLaunchKernelGGL(sum_partials2_kernel, dim3((C + 7) / 8), dim3(256), 0, st, pa, pb, nparts, C, oa, ob);
+}
+
 struct StatFn {
     const float* x; int C;
     __device__ __forceinline__ void operator()(int64_t r, int c, f32x4& a, f32x4& b) const {
@@ -696,6 +781,12 @@ extern "C" int bdetr_bn_stats(const float* x, int64_t rows, int C, const float* 
                     "bdetr_bn_stats: partial sums required (use bdetr_colstats to produce them from x)");
     (void)x;
     hipStream_t st = (hipStream_t)stream;
+    if (nparts >= wide_reduce_min() && C % 4 == 0 && (reinterpret_cast<uintptr_t>(part_sum) | reinterpret_cast<uintptr_t>(part_sq)) % 16 == 0) {
+        (void)fold_ws;
+        hipLaunchKernelGGL(reduce_partials2_kernel<true>, dim3(C / 4), dim3(256), 0, st, part_sum, part_sq, nparts, C, (float*)nullptr, (float*)nullptr,
+                           BnFinalizeArgs{rows, eps, momentum, bessel, mean, rstd, moving_mean, moving_var, guard_flag});
+        return bdetr_launch_status("bn_finalize");
+    }
     if (nparts > 4 * BN_FOLD && fold_ws != nullptr) {
         // many epilogue partials (one per 32/64 output rows): fold them to BN_FOLD rows with a wide grid first
         float* fa = fold_ws; float* fb = fold_ws + (int64_t)BN_FOLD * C;
@@ -748,7 +839,7 @@ extern "C" int bdetr_bn_bwd(const float* dout, const float* out, const float* x,
     float* pa = ws; float* pb = ws + (int64_t)nch * C;
     BnBwdFn f{dout, out, x, mean, rstd, gamma, beta, C, relu};
     hipLaunchKernelGGL((colreduce2_kernel<BnBwdFn>), dim3(g.gx, nch), dim3(256), 0, st, f, rows, C, g.tx, rpc, pa, pb);
-    hipLaunchKernelGGL(sum_partials2_kernel, dim3((C + 7) / 8), dim3(256), 0, st, pa, pb, nch, C, dbeta, dgamma);
+    sum_partials2(pa, pb, nch, C, dbeta, dgamma, st);
     int64_t n4 = rows * C / 4;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(n4, 256, 2)), dim3(256), 0, st, dout, out, x, mean, rstd, gamma, beta, dgamma, dbeta,
                        relu, frozen, dx, dresidual, n4, C / 4, 1.0f / (float)rows);
@@ -781,7 +872,7 @@ extern "C" int bdetr_stem_pool_bwd(const float* dpool, const uint8_t* tap, const
     float* pa = ws; float* pb = ws + (int64_t)nch * C;
     StemBwdFn f{dpool, reinterpret_cast<const unsigned*>(tap), y, mean, rstd, gamma, beta, s};
     hipLaunchKernelGGL((colreduce2_kernel<StemBwdFn>), dim3(g.gx, nch), dim3(256), 0, st, f, rows, C, g.tx, rpc, pa, pb);
-    hipLaunchKernelGGL(sum_partials2_kernel, dim3((C + 7) / 8), dim3(256), 0, st, pa, pb, nch, C, dbeta, dgamma);
+    sum_partials2(pa, pb, nch, C, dbeta, dgamma, st);
     const int64_t n4 = rows * C / 4;
     hipLaunchKernelGGL(stem_bwd_apply_kernel, dim3(ew_grid(n4, 256, 2)), dim3(256), 0, st, dpool, reinterpret_cast<const unsigned*>(tap), y, mean, rstd, gamma, beta,
                        dgamma, dbeta, s, dy, n4, 1.0f / (float)rows);
@@ -837,11 +928,11 @@ extern "C" int bdetr_bn_bwd_p16(const float* dout, const void* out, int out_p16,
     int nch = (int)cdiv64(rows, rpc);
     float* pa = ws; float* pb = ws + (int64_t)nch * C;
     if (pre_g != nullptr) {
-        hipLaunchKernelGGL(sum_partials2_kernel, dim3((C + 7) / 8), dim3(256), 0, st, pre_g, pre_gx, pre_n, C, dbeta, dgamma);
+        sum_partials2(pre_g, pre_gx, pre_n, C, dbeta, dgamma, st);
     } else {
         BnBwdFn f{dout, reinterpret_cast<const float*>(out), x, mean, rstd, gamma, beta, C, relu, out_p16};
         hipLaunchKernelGGL((colreduce2_kernel<BnBwdFn>), dim3(g.gx, nch), dim3(256), 0, st, f, rows, C, g.tx, rpc, pa, pb);
-        hipLaunchKernelGGL(sum_partials2_kernel, dim3((C + 7) / 8), dim3(256), 0, st, pa, pb, nch, C, dbeta, dgamma);
+        sum_partials2(pa, pb, nch, C, dbeta, dgamma, st);
     }
     const int64_t n4 = rows * C / 4;
     hipLaunchKernelGGL(bn_bwd_apply_p16_kernel, dim3(ew_grid(n4, 256, 2)), dim3(256), 0, st, dout, out, out_p16, x, mean, rstd, gamma, beta, dgamma, dbeta,
@@ -873,7 +964,7 @@ extern "C" int bdetr_add_dropout_layernorm_bwd(const float* dout, const float* x
     float* pg = ws; float* pb = ws + (int64_t)nch * D;
     hipLaunchKernelGGL(add_drop_ln_bwd_kernel, dim3(nch), dim3(256), 0, st, dout, x, y, gamma, mean, rstd, dx, dy, pg, pb,
                        rows, D, rpc, rate, seed, accumulate_dx, seed_base);
-    hipLaunchKernelGGL(sum_partials2_kernel, dim3((D + 7) / 8), dim3(256), 0, st, pg, pb, nch, D, dgamma, dbeta);
+    sum_partials2(pg, pb, nch, D, dgamma, dbeta, st);
     return bdetr_launch_status("add_dropout_layernorm_bwd");
 }
 
