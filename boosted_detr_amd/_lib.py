@@ -97,6 +97,7 @@ SIGNATURES = {
     "bdetr_conv2d_bwd_weight_splitk": (I, [C.POINTER(ConvDesc)]),
     "bdetr_bn_apply_p16": (I, [P, P, P, P, P, P, I, C.POINTER(BnAffine), I, P, P, P, P, P, L, I, P]),
     "bdetr_bn_bwd_p16": (I, [P, P, I, P, P, P, P, P, I, I, P, P, P, P, P, P, P, P, I, L, I, P]),
+    "bdetr_bn_bwd_p16_even_pixels": (I, [P, P, I, P, P, P, P, P, I, I, P, P, P, P, P, P, I, I, I, I, P]),
     "bdetr_p16_supported": (I, [C.POINTER(ConvDesc)]),
     "bdetr_p16_pack": (I, [P, L, P, P, P, P]),
     "bdetr_p16_unpack": (I, [P, I, L, P, P]),
@@ -133,6 +134,7 @@ SIGNATURES = {
     "bdetr_bn_bwd": (I, [P, P, P, P, P, P, P, I, I, P, P, P, P, P, L, I, P]),
     "bdetr_maxpool3x3s2_fwd": (I, [P, P, I, I, I, I, I, I, P]),
     "bdetr_maxpool3x3s2_bwd": (I, [P, P, P, P, I, I, I, I, I, I, P]),
+    "bdetr_stem_pool_bwd_chunks": (I, [L]),
     "bdetr_stem_pool_fwd": (I, [P, P, P, P, P, I, I, I, I, P, P, P, P, P]),
     "bdetr_stem_pool_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, P, P, P, P, P]),
     "bdetr_attention_head_dim": (I, []),

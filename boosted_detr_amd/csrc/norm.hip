@@ -267,7 +267,15 @@ struct BnBwdFn {   // a = g (masked dout), b = g * xhat
     const float* dout; const float* out; const float* x; const float* mean; const float* rstd; const float* gamma; const float* beta;
     int C; int relu;
     int out_p16 = 0;      // mask source `out`: 0 fp32 forward output, 1 its bf16 pair copy (P16 layout), 2 bn_apply_p16's ReLU bit mask
+    // even_h > 0: dout is zero outside the pixels (2i, 2j) of an [N, even_h, even_w] grid (it came out of the backward-data of stride-2
+    // 1x1 convolutions): the reduction then runs over the N * ceil(H/2) * ceil(W/2) rows that can be non-zero, `r` counts those
+    int even_h = 0, even_w = 0;
     __device__ __forceinline__ void operator()(int64_t r, int c, f32x4& a, f32x4& b) const {
+        if (even_h > 0) {
+            const unsigned w2 = (unsigned)(even_w + 1) >> 1, h2 = (unsigned)(even_h + 1) >> 1;
+            const unsigned q = (unsigned)r, j2 = q % w2, t = q / w2, i2 = t % h2, n = t / h2;
+            r = ((int64_t)n * even_h + 2 * i2) * even_w + 2 * j2;
+        }
         f32x4 g = *reinterpret_cast<const f32x4*>(dout + r * C + c);
         f32x4 xv = *reinterpret_cast<const f32x4*>(x + r * C + c);
         f32x4 m = *reinterpret_cast<const f32x4*>(mean + c);
@@ -413,20 +421,29 @@ __device__ __forceinline__ f32x4 stem_pixel_grad(const float* __restrict__ dpool
     const int c4n = s.C / 4, c4 = c / 4;
     const int iw = (int)(px % (unsigned)s.W); const unsigned t = px / (unsigned)s.W;
     const int ih = (int)(t % (unsigned)s.H), n = (int)(t / (unsigned)s.H);
-    // windows ph with 2 ph - 1 <= ih <= 2 ph + 1: ih / 2 and, for odd ih, (ih + 1) / 2
+    // windows ph with 2 ph - 1 <= ih <= 2 ph + 1: ih / 2 and, for odd ih, (ih + 1) / 2 - always FOUR candidate windows, all eight
+    // loads issued before the first compare (a candidate that does not exist re-reads a real window and is given a tap id no byte holds;
+    // the data-dependent 1..2 x 1..2 loop this replaces left one load in flight per lane: 454 us for the reduction pass, round 4)
     const int ph0 = ih >> 1, pw0 = iw >> 1;
-    const int nph = 1 + ((ih & 1) & (int)(ph0 + 1 < s.PH)), npw = 1 + ((iw & 1) & (int)(pw0 + 1 < s.PW));
-    f32x4 g = {0.f, 0.f, 0.f, 0.f};
-    for (int a = 0; a < nph; ++a)
-        for (int b = 0; b < npw; ++b) {
-            const int ph = ph0 + a, pw = pw0 + b;
-            const int64_t o = (((int64_t)n * s.PH + ph) * s.PW + pw) * c4n + c4;
-            const unsigned mine = (unsigned)((ih - (ph * 2 - 1)) * 3 + (iw - (pw * 2 - 1)));
-            const unsigned word = tap[o];
-            const f32x4 dv = reinterpret_cast<const f32x4*>(dpool)[o];
+    const bool two_h = (ih & 1) & (int)(ph0 + 1 < s.PH), two_w = (iw & 1) & (int)(pw0 + 1 < s.PW);
+    unsigned word[4];
+    f32x4 dv[4];
+    unsigned mine[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) if (((word >> (8 * e)) & 0xFFu) == mine) g[e] += dv[e];
-        }
+    for (int k = 0; k < 4; ++k) {
+        const int a = k >> 1, b = k & 1;
+        const bool real = (a == 0 || two_h) && (b == 0 || two_w);
+        const int ph = ph0 + (a & (int)two_h), pw = pw0 + (b & (int)two_w);
+        const int64_t o = (((int64_t)n * s.PH + ph) * s.PW + pw) * c4n + c4;
+        mine[k] = real ? (unsigned)((ih - (ph * 2 - 1)) * 3 + (iw - (pw * 2 - 1))) : 0xFFu;
+        word[k] = tap[o];
+        dv[k] = reinterpret_cast<const f32x4*>(dpool)[o];
+    }
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)           // same order as the loop it replaces: (ph0, pw0), (ph0, pw0 + 1), (ph0 + 1, pw0), (ph0 + 1, pw0 + 1)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (((word[k] >> (8 * e)) & 0xFFu) == mine[k]) g[e] += dv[k][e];
     xhat = (yv - m) * rs;
 #pragma unroll
     for (int e = 0; e < 4; ++e) if (!(bn_affine(yv[e], m[e], rs[e], gm[e], bt[e]) > 0.f)) g[e] = 0.f;
@@ -858,6 +875,9 @@ extern "C" int bdetr_stem_pool_fwd(const float* y, const float* mean, const floa
     return bdetr_launch_status("stem_pool_fwd");
 }
 
+constexpr int STEM_BWD_CHUNKS = 2048;
+extern "C" int bdetr_stem_pool_bwd_chunks(int64_t rows) { return (int)cdiv64(rows, chunk_rows_for(rows, STEM_BWD_CHUNKS, 64)); }
+
 extern "C" int bdetr_stem_pool_bwd(const float* dpool, const uint8_t* tap, const float* y, const float* mean, const float* rstd, const float* gamma,
                                    const float* beta, int N, int H, int W, int C, float* dy, float* dgamma, float* dbeta, float* ws, void* stream) {
     BDETR_CHECK_ARG(dpool && tap && y && mean && rstd && gamma && beta && dy && dgamma && dbeta && ws && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0,
@@ -867,7 +887,8 @@ extern "C" int bdetr_stem_pool_bwd(const float* dpool, const uint8_t* tap, const
     const StemGeom s{N, H, W, C, (H + 2 - 3) / 2 + 1, (W + 2 - 3) / 2 + 1};
     const int64_t rows = (int64_t)N * H * W;
     ColGeom g = col_geom(C);
-    int64_t rpc = chunk_rows_for(rows, chunks_for_width(g.gx), 64);   // <= bdetr_bn_bwd_chunks(rows), which sizes ws
+    // (64 channels = ONE column block: 2048 row chunks instead of bn_bwd's 512, or a quarter of the chip's wave slots stay empty)
+    int64_t rpc = chunk_rows_for(rows, STEM_BWD_CHUNKS, 64);
     int nch = (int)cdiv64(rows, rpc);
     float* pa = ws; float* pb = ws + (int64_t)nch * C;
     StemBwdFn f{dpool, reinterpret_cast<const unsigned*>(tap), y, mean, rstd, gamma, beta, s};
@@ -914,10 +935,10 @@ extern "C" int bdetr_relu_mask_apply(float* x, const uint64_t* relu_mask, int64_
     return bdetr_launch_status("relu_mask_apply");
 }
 
-extern "C" int bdetr_bn_bwd_p16(const float* dout, const void* out, int out_p16, const float* x, const float* mean,
-                                const float* rstd, const float* gamma, const float* beta, int relu, int frozen,
-                                float* dx32, void* dx_bf16, float* dgamma, float* dbeta, float* dresidual,
-                                float* ws, const float* pre_g, const float* pre_gx, int pre_n, int64_t rows, int C, void* stream) {
+static int bn_bwd_p16_impl(const float* dout, const void* out, int out_p16, const float* x, const float* mean,
+                           const float* rstd, const float* gamma, const float* beta, int relu, int frozen,
+                           float* dx32, void* dx_bf16, float* dgamma, float* dbeta, float* dresidual,
+                           float* ws, const float* pre_g, const float* pre_gx, int pre_n, int64_t rows, int C, int even_h, int even_w, void* stream) {
     BDETR_CHECK_ARG(dout && x && mean && rstd && gamma && dx_bf16 && dgamma && dbeta && (ws || pre_g) && rows > 0 && C > 0 && C % 8 == 0,
                     "bdetr_bn_bwd_p16: bad arguments (C %% 8 == 0 required)");
     BDETR_CHECK_ARG((pre_g == nullptr) == (pre_gx == nullptr) && (pre_g == nullptr || pre_n > 0), "bdetr_bn_bwd_p16: pre_g / pre_gx / pre_n inconsistent");
@@ -930,14 +951,38 @@ extern "C" int bdetr_bn_bwd_p16(const float* dout, const void* out, int out_p16,
     if (pre_g != nullptr) {
         sum_partials2(pre_g, pre_gx, pre_n, C, dbeta, dgamma, st);
     } else {
-        BnBwdFn f{dout, reinterpret_cast<const float*>(out), x, mean, rstd, gamma, beta, C, relu, out_p16};
-        hipLaunchKernelGGL((colreduce2_kernel<BnBwdFn>), dim3(g.gx, nch), dim3(256), 0, st, f, rows, C, g.tx, rpc, pa, pb);
+        BnBwdFn f{dout, reinterpret_cast<const float*>(out), x, mean, rstd, gamma, beta, C, relu, out_p16, even_h, even_w};
+        int64_t red_rows = rows;
+        if (even_h > 0) {
+            red_rows = rows / ((int64_t)even_h * even_w) * ((even_h + 1) / 2) * ((even_w + 1) / 2);
+            rpc = chunk_rows_for(red_rows, chunks_for_width(g.gx), 64);
+            nch = (int)cdiv64(red_rows, rpc);
+            pb = ws + (int64_t)nch * C;
+        }
+        hipLaunchKernelGGL((colreduce2_kernel<BnBwdFn>), dim3(g.gx, nch), dim3(256), 0, st, f, red_rows, C, g.tx, rpc, pa, pb);
         sum_partials2(pa, pb, nch, C, dbeta, dgamma, st);
     }
     const int64_t n4 = rows * C / 4;
     hipLaunchKernelGGL(bn_bwd_apply_p16_kernel, dim3(ew_grid(n4, 256, 2)), dim3(256), 0, st, dout, out, out_p16, x, mean, rstd, gamma, beta, dgamma, dbeta,
                        relu, frozen, dx32, dx_bf16, dresidual, n4, C / 4, 1.0f / (float)rows);
     return bdetr_launch_status("bn_bwd_p16");
+}
+
+extern "C" int bdetr_bn_bwd_p16(const float* dout, const void* out, int out_p16, const float* x, const float* mean,
+                                const float* rstd, const float* gamma, const float* beta, int relu, int frozen,
+                                float* dx32, void* dx_bf16, float* dgamma, float* dbeta, float* dresidual,
+                                float* ws, const float* pre_g, const float* pre_gx, int pre_n, int64_t rows, int C, void* stream) {
+    return bn_bwd_p16_impl(dout, out, out_p16, x, mean, rstd, gamma, beta, relu, frozen, dx32, dx_bf16, dgamma, dbeta, dresidual, ws, pre_g, pre_gx, pre_n,
+                           rows, C, 0, 0, stream);
+}
+
+extern "C" int bdetr_bn_bwd_p16_even_pixels(const float* dout, const void* out, int out_p16, const float* x, const float* mean,
+                                            const float* rstd, const float* gamma, const float* beta, int relu, int frozen,
+                                            float* dx32, void* dx_bf16, float* dgamma, float* dbeta, float* dresidual,
+                                            float* ws, int N, int H, int W, int C, void* stream) {
+    BDETR_CHECK_ARG(N > 0 && H > 0 && W > 0 && ws && (int64_t)N * H * W < (int64_t)1 << 31, "bdetr_bn_bwd_p16_even_pixels: bad geometry");
+    return bn_bwd_p16_impl(dout, out, out_p16, x, mean, rstd, gamma, beta, relu, frozen, dx32, dx_bf16, dgamma, dbeta, dresidual, ws, nullptr, nullptr, 0,
+                           (int64_t)N * H * W, C, H, W, stream);
 }
 
 extern "C" int bdetr_add_dropout_layernorm_fwd(const float* x, const float* y, const float* gamma, const float* beta,

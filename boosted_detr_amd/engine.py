@@ -236,6 +236,8 @@ class Tape:
                         del have._bnb_parts
                     if hasattr(have, "_bnb_parts_shortcut"):
                         del have._bnb_parts_shortcut
+                    if hasattr(have, "_even_pixels"):      # (ops.conv_bn's tag of a gradient that is zero off the even pixels: no longer true)
+                        del have._even_pixels
                     if getattr(have, "_bdetr_owned", False):       # sole owner: accumulate in place
                         K.axpy_(1.0, g.view(have.shape), have)
                     else:

@@ -370,7 +370,7 @@ def bn_apply_p16(x2d, mean, rstd, gamma, beta, residual=None, relu=False, want_f
 
 
 def bn_bwd_p16(dout, out, x2d, mean, rstd, gamma, relu, frozen, want_residual_grad=False, dgamma=None, dbeta=None, beta=None, want_fp32=False,
-               out_p16=False, pre=None):
+               out_p16=False, pre=None, even_pixels=None):
     """bn_bwd writing the input gradient as a bf16 pair: returns (dx_bf16, dx32 | None, dgamma, dbeta, dres | None).
     out_p16: what the ReLU mask source `out` is - 0 / False the fp32 forward output, 1 / True its bf16 pair copy, 2 the bit
     mask of bn_apply_p16(want_mask=True)."""
@@ -386,6 +386,13 @@ def bn_bwd_p16(dout, out, x2d, mean, rstd, gamma, relu, frozen, want_residual_gr
     dres = torch.empty_like(x2d) if want_residual_grad else None
     # pre = (part_g, part_gx, nparts): the reduction already done by the backward-data epilogue that produced dout
     ws = empty(2 * Cc * L.bdetr_bn_bwd_chunks(rows), like=x2d) if pre is None else None
+    if even_pixels is not None and pre is None:
+        # dout [N,H,W,C] is zero outside the pixels (2i, 2j) (ops.conv_bn tags such gradients): the reduction visits those only
+        N, H, W = even_pixels
+        assert N * H * W == rows
+        check(L.bdetr_bn_bwd_p16_even_pixels(_p(dout), _p(out), int(out_p16), _p(x2d), _p(mean), _p(rstd), _p(gamma), _p(beta), int(relu), int(frozen),
+                                             _p(dx32), _p(dxb), _p(dgamma), _p(dbeta), _p(dres), _p(ws), N, H, W, Cc, _stream()), "bn_bwd_p16_even_pixels")
+        return dxb, dx32, dgamma, dbeta, dres
     pg, pgx, pn = pre if pre is not None else (None, None, 0)
     check(L.bdetr_bn_bwd_p16(_p(dout), _p(out), int(out_p16), _p(x2d), _p(mean), _p(rstd), _p(gamma), _p(beta), int(relu), int(frozen), _p(dx32),
                              _p(dxb), _p(dgamma), _p(dbeta), _p(dres), _p(ws), _p(pg), _p(pgx), int(pn), rows, Cc, _stream()), "bn_bwd_p16")
@@ -718,7 +725,7 @@ def stem_pool_bwd(dpool, tap, y, mean, rstd, gamma, beta, dgamma=None, dbeta=Non
     dy = torch.empty_like(y)
     dgamma = empty(Cc, like=y) if dgamma is None else dgamma
     dbeta = empty(Cc, like=y) if dbeta is None else dbeta
-    ws = empty(2 * Cc * L.bdetr_bn_bwd_chunks(N * H * W), like=y)
+    ws = empty(2 * Cc * L.bdetr_stem_pool_bwd_chunks(N * H * W), like=y)
     check(L.bdetr_stem_pool_bwd(_p(dpool), _p(tap), _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), N, H, W, Cc, _p(dy), _p(dgamma), _p(dbeta),
                                 _p(ws), _stream()), "stem_pool_bwd")
     return dy, dgamma, dbeta

@@ -162,6 +162,7 @@ P16_ENABLED = [os.environ.get("BDETR_P16", "1") != "0"]
 # bdetr_p16_conv2d_bwd_weight_xf16), so activations have no bf16 pair copy at all: bn_apply_p16 writes 4 bytes per element less.
 WGRAD_XF16 = os.environ.get("BDETR_WGRAD_XF16", "1") != "0"
 BF16_FOR_3X3 = os.environ.get("BDETR_BF16_3X3", "1") != "0"       # ... except in front of a 3x3 convolution (conv_bn want_bf16)
+EVEN_PIXELS = os.environ.get("BDETR_EVEN_PIXELS", "1") != "0"  # stage-last BatchNorm backward reduces over the even pixels only (conv_bn.backward)
 LAZY_SKIP = os.environ.get("BDETR_LAZY_SKIP", "1") != "0"      # residual units hand their skip gradient on unmasked (conv_bn.backward)
 
 
@@ -323,9 +324,12 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
             bn_relu = relu
             if lazy_bits is not None:                       # this BatchNorm has no ReLU of its own: apply the incoming mask instead
                 mask_src, mode, bn_relu = lazy_bits, 2, True
+            even = getattr(g_out, "_even_pixels", None) if EVEN_PIXELS else None     # zero off the even pixels: a quarter-size reduction pass
+            if even is not None and even != (N, g.OH, g.OW):
+                even = None
             dyb, _, _, _, dres = K.bn_bwd_p16(g2d, mask_src, y2d, mean, rstd, bn.gamma.value, bn_relu, False,
                                               want_residual_grad=want_res and not lazy_skip,
-                                              dgamma=sg.buf, dbeta=sb.buf, beta=bn.beta.value, out_p16=mode, pre=pre)
+                                              dgamma=sg.buf, dbeta=sb.buf, beta=bn.beta.value, out_p16=mode, pre=pre, even_pixels=even)
             if lazy_skip:
                 dres = _own(g_out.view(residual.shape))
                 dres._lazy_mask = relu_bits
@@ -350,6 +354,7 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
                         s.commit()
                 side_task(param_grads, xw, dyb)
             dx = None
+            s2 = R == 1 and S == 1 and stride == 2 and pad == 0
             if x_needs_grad:
                 _, wt = packed_weights(w, need_bwd=True)
                 ctx = getattr(x_handle, "_bn_ctx", None)
@@ -368,6 +373,8 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
                         del acc[0]._lazy_mask
                     else:
                         K.p16_conv2d_bwd_data(dyb4, wt, g, dx=materialise(acc[0]).view(N, H, W, Cin), accumulate=True)
+                    if hasattr(acc[0], "_even_pixels") and not (s2 and acc[0]._even_pixels == (N, H, W)):
+                        del acc[0]._even_pixels         # this contribution is dense
                     dx = acc[0]
                 elif ctx is not None and stride == 1:
                     dx, parts = K.p16_conv2d_bwd_data_bnstats(dyb4, wt, g, *ctx)
@@ -375,6 +382,10 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
                     dx._bnb_parts = parts
                 else:
                     dx = _own(K.p16_conv2d_bwd_data(dyb4, wt, g))
+                    if s2:
+                        # a stride-2 1x1 convolution's input gradient: zero-filled, then written at the pixels (2i, 2j) only.  The tag lets
+                        # the producer's BatchNorm backward reduce over those pixels alone (it survives further stride-2 1x1 contributions)
+                        dx._even_pixels = (N, H, W)
             return dx, ((dres if lazy_skip else _own(dres.view(residual.shape))) if want_res else None)
         x32 = as_fp32(x)
         out32 = out2d if (out2d is not None or not (relu and want_res)) else _2d(as_fp32(out))
@@ -402,6 +413,8 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
             if acc is not None and acc[0] is not None:
                 # residual merge fused into the GEMM epilogue: dx += conv_transpose(dy) (no separate add pass)
                 dx = K.conv2d_bwd_data(dy4, w.value, g, dx=materialise(acc[0]).view(N, H, W, Cin), accumulate=True)
+                if hasattr(acc[0], "_even_pixels"):
+                    del acc[0]._even_pixels
                 dx = acc[0]
             else:
                 dx = _own(K.conv2d_bwd_data(dy4, w.value, g))
@@ -543,6 +556,8 @@ def dense(x: torch.Tensor, w: Variable, b: Variable, act: int = K.ACT_NONE) -> t
         if have is not None and have.is_contiguous() and have.shape == x.shape:
             # another consumer's gradient of x is already there: add into it in the GEMM epilogue (no separate axpy pass)
             K.linear_bwd_data(g2d, w.value, dx=_2d(materialise(have)), accumulate=True)
+            if hasattr(have, "_even_pixels"):
+                del have._even_pixels
             return (have,)
         return (_own(K.linear_bwd_data(g2d, w.value).view(x.shape)),)
 

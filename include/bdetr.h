@@ -193,6 +193,13 @@ int bdetr_bn_bwd_p16(const float* dout, const void* out, int out_p16, const floa
                      float* ws, const float* pre_g, const float* pre_gx, int pre_n, int64_t rows, int C, void* stream);
 /* pre_g / pre_gx [pre_n][C] (may be null): partial sums of g and g * xhat already produced by the backward-data
  * epilogue that wrote dout (bdetr_p16_conv2d_bwd_data_bnstats); the reduction pass over dout and x is skipped. */
+/* The same for a dout [N,H,W,C] that is zero outside the pixels (2i, 2j): the gradient of a stage's last unit, which reaches it only
+ * through the backward-data of the next stage's stride-2 1x1 convolutions (keras ResNet50 conv{3,4,5}_block1_{0,1}_conv).  The
+ * reduction pass visits those N * ceil(H/2) * ceil(W/2) rows only - a quarter of the bytes; the apply pass is the dense one. */
+int bdetr_bn_bwd_p16_even_pixels(const float* dout, const void* out, int out_p16, const float* x, const float* mean,
+                                 const float* rstd, const float* gamma, const float* beta, int relu, int frozen,
+                                 float* dx32, void* dx_bf16, float* dgamma, float* dbeta, float* dresidual,
+                                 float* ws, int N, int H, int W, int C, void* stream);
 int bdetr_p16_supported(const bdetr_conv_desc* d);
 int bdetr_p16_pack(const float* x, int64_t n, void* f16_out, void* bf16_out, int* overflow_flag, void* stream);
 int bdetr_p16_unpack(const void* p, int is_f16, int64_t n, float* out, void* stream);
@@ -350,7 +357,8 @@ int bdetr_maxpool3x3s2_bwd(const float* x, const float* y, const float* dy, floa
  * fwd: pooled tensor [N,PH,PW,C] (PH = (H-1)/2+1) as fp32 (out32) and / or as the f16 pair of the P16 layout (out_f16), plus
  *      tap [N,PH,PW,C] bytes: which of the window's 9 taps (row-major) held the maximum - the first one on a tie.
  * bwd: dpool [N,PH,PW,C] -> dy [N,H,W,C] (gradient of the raw conv output), dgamma, dbeta; the normalised full-resolution tensor
- *      and its gradient are never materialised.  ws: 2*C*bdetr_bn_bwd_chunks(N*H*W) floats.  C % 8 == 0, N*H*W < 2^31. */
+ *      and its gradient are never materialised.  ws: 2*C*bdetr_stem_pool_bwd_chunks(N*H*W) floats.  C % 8 == 0, N*H*W < 2^31. */
+int bdetr_stem_pool_bwd_chunks(int64_t rows);
 int bdetr_stem_pool_fwd(const float* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
                         int N, int H, int W, int C, float* out32, void* out_f16, uint8_t* tap, int* overflow_flag, void* stream);
 int bdetr_stem_pool_bwd(const float* dpool, const uint8_t* tap, const float* y, const float* mean, const float* rstd, const float* gamma,

@@ -349,3 +349,56 @@ def test_halo_resident_weight_gradient_kernel_matches_too(cuda):
                         "test_p16_conv_fwd_bwd and (40-40-256 or 20-20-512 or 80-80-128 or 14-14-256)"], env=env, capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-1000:]
     assert int(r.stdout.strip().splitlines()[-1].split(" passed")[0].split()[-1]) >= 4, r.stdout[-500:]
+
+
+@pytest.mark.parametrize("N,H,W,C", [(2, 20, 20, 256), (3, 9, 7, 64), (16, 80, 80, 512), (1, 1, 1, 8)])
+def test_bn_backward_reduces_over_the_even_pixels_of_a_strided_gradient(cuda, N, H, W, C):
+    """bdetr_bn_bwd_p16_even_pixels: the gradient of a stage's last unit arrives through stride-2 1x1 convolutions and is zero off the
+    pixels (2i, 2j); the reduction pass over those pixels alone gives the dgamma / dbeta / dx of the dense pass (the skipped rows add
+    exact zeros: 1e-6 for the summation order), and the real producer of such a gradient - the stride-2 backward-data - is what
+    ops.conv_bn tags."""
+    from boosted_detr_amd import kernels as k
+    rows = N * H * W
+    y = dev(rnd(rows, C, seed=1) * 2 + 0.3)
+    gamma, beta = dev(1 + 0.1 * rnd(C, seed=2)), dev(0.1 * rnd(C, seed=3))
+    mean, rstd = k.bn_stats(rows, C, k.colstats(y), 1.001e-5, 0.99, True, dev(torch.zeros(C)), dev(torch.ones(C)), like=y)
+    resid = dev(rnd(rows, C, seed=4))
+    _, _, _, bits_ = k.bn_apply_p16(y, mean, rstd, gamma, beta, resid, True, want_f16=False, want_bf16=False, want_mask=True)
+    g = rnd(N, H, W, C, seed=5)
+    keep = torch.zeros(N, H, W, 1)
+    keep[:, ::2, ::2] = 1
+    dout = dev(g * keep).view(rows, C)
+    ref = k.bn_bwd_p16(dout, bits_, y, mean, rstd, gamma, True, False, want_residual_grad=True, beta=beta, want_fp32=True, out_p16=2)
+    got = k.bn_bwd_p16(dout, bits_, y, mean, rstd, gamma, True, False, want_residual_grad=True, beta=beta, want_fp32=True, out_p16=2, even_pixels=(N, H, W))
+    close(got[2], ref[2], rtol=1e-6)
+    close(got[3], ref[3], rtol=1e-6)
+    close(got[1], ref[1], rtol=1e-6)
+    assert torch.equal(got[4], ref[4])
+
+
+def test_stride2_backward_data_gradients_carry_the_even_pixel_tag(cuda):
+    """Two stride-2 1x1 consumers of one tensor (the next stage's c1 and projection shortcut): the accumulated input gradient keeps
+    the tag and IS zero off the even pixels; a dense contribution drops it."""
+    from boosted_detr_amd import kernels as k, ops
+    from boosted_detr_amd.backbone import _ConvBN
+    from boosted_detr_amd.engine import Tape, join_side_stream, recording
+    N, H, C = 2, 12, 64
+    a, b, d = (_ConvBN("t/", f"c{i}", f"b{i}", C, 128, 1, s, 0, seed=i) for i, s in ((1, 2), (2, 2), (3, 1)))
+    x32 = dev(rnd(N, H, H, C, seed=1)).relu_()
+    seen = {}
+    with k.gemm_precision("split"):
+        for layers in ((a, b), (d, a, b)):
+            x = x32.clone()
+            xf, _ = k.p16_pack(x, want_f16=True, want_bf16=False)
+            x._p16f, x._p16b = xf, None
+            tape = Tape()
+            with recording(tape):
+                outs = [l([x], training=True, relu=True, want_fp32=True) for l in layers]
+            grads = tape.backward({id(o): dev(rnd(*o.shape, seed=7 + i)) for i, o in enumerate(outs)})
+            join_side_stream()
+            seen[len(layers)] = grads[id(x)]
+    sparse, dense = seen[2], seen[3]
+    assert getattr(sparse, "_even_pixels", None) == (N, H, H) and not hasattr(dense, "_even_pixels")
+    off = sparse.clone()
+    off[:, ::2, ::2] = 0
+    assert float(off.abs().max()) == 0.0 and float(sparse.abs().max()) > 0
