@@ -10,10 +10,13 @@ rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
 B="--no-cpu-baseline --no-roofline --no-batch32 --no-fp32-policy --no-configs2"
 python bench.py --steps 40 --warmup 5 > $OUT/r04_bench_line.json 2> $OUT/bench.err || { tail -20 $OUT/bench.err; exit 1; }
+BDETR_PROF_DUMP=$OUT/launches.csv python bench.py --steps 10 --warmup 3 --no-graph --no-cpu-baseline --no-batch32 --no-fp32-policy --no-configs2 > $OUT/bench_launches.json 2> $OUT/bench_launches.err || { tail -20 $OUT/bench_launches.err; exit 1; }
+python tools/launch_roofline.py $OUT/launches.csv 10 > $OUT/r04_launch_roofline.txt
 python bench.py --steps 40 --warmup 5 --no-graph $B > $OUT/r04_bench_line_eager.json 2> $OUT/bench_eager.err || { tail -20 $OUT/bench_eager.err; exit 1; }
 BDETR_DETERMINISTIC=1 python bench.py --steps 40 --warmup 5 $B > $OUT/r04_bench_line_deterministic.json 2> $OUT/bench_det.err || { tail -20 $OUT/bench_det.err; exit 1; }
 BDETR_SIDE_STREAM=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/serial -- python3 bench.py --steps 5 --warmup 2 --no-graph $B > $OUT/serial.log 2>&1 || { tail -20 $OUT/serial.log; exit 1; }
 find $OUT/serial -name "*kernel_stats.csv" -exec cp {} $OUT/r04_kernel_stats_serial.csv \;
+python tools/kernel_by_grid.py "$(find $OUT/serial -name '*kernel_trace.csv' | head -1)" 7 > $OUT/r04_kernel_by_grid_serial.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/side -- python3 bench.py --steps 5 --warmup 2 --no-graph $B > $OUT/side.log 2>&1 || { tail -20 $OUT/side.log; exit 1; }
 find $OUT/side -name "*kernel_stats.csv" -exec cp {} $OUT/r04_kernel_stats_side_stream.csv \;
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/graph -- python3 bench.py --steps 5 --warmup 2 $B > $OUT/graph.log 2>&1 || { tail -20 $OUT/graph.log; exit 1; }
