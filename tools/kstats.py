@@ -14,7 +14,7 @@ for r in rows:
     short = re.sub(r'\(.*', '', short)[:110]
     if t > min_ms:
         print(f"{t:7.3f} ms {c:6.1f} calls {float(r['AverageNs'])/1e3:8.1f} us  {short}")
-    key = ('igemm' if 'igemm_kernel' in n else 'hconv' if 'hconv_kernel' in n else 'sgemm' if 'sgemm_kernel' in n else 'bn' if re.search(r'bn_|BnBwd|sum_partials|fold_partials|StatFn', n)
+    key = ('igemm' if 'igemm_kernel' in n else 'hconv' if 'hconv_kernel' in n else 'sgemm' if 'sgemm_kernel' in n else 'bn' if re.search(r'bn_|BnBwd|sum_partials|fold_partials|StatFn|stem_|StemBwd', n)
            else 'p16pack' if 'p16_' in n else 'attn' if 'attn' in n else 'other')
     fam[key] = fam.get(key, 0) + t
 print({k: round(v, 2) for k, v in sorted(fam.items())})
