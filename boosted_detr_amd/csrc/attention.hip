@@ -41,6 +41,13 @@ constexpr int AD = 32;            // head dimension
 constexpr int ALD = AD + 4;       // LDS row stride (floats): conflict-free 16-byte row reads
 constexpr int CH = 64;            // streamed rows per chunk
 constexpr int COLS_PER_BLOCK = 128;
+// Chunks of look-ahead of the streamed operand pair (a ring of register sets).  Measured round 4 (-DBDETR_ATTN_PF=3 against 1, whole step,
+// three alternating runs each on one box): 604.1 against 604.9 images/s - with three workgroups resident per CU the other workgroups
+// cover a chunk's HBM round trip already; 1 keeps the registers.
+#ifndef BDETR_ATTN_PF
+#define BDETR_ATTN_PF 1
+#endif
+constexpr int APF = BDETR_ATTN_PF;
 
 __device__ __forceinline__ int crow(int e, int lh) { return (e & 3) + 8 * (e >> 2) + 4 * lh; }   // accumulator row of register e
 
@@ -237,13 +244,21 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     float m = -INFINITY, l = 0.f;
 
     const bool wave_active = blockIdx.x * COLS_PER_BLOCK + wave * 32 < nq;      // wave-uniform: idle waves only help loading
-    ChunkRegs ck = fetch_chunk(kbase, D, 0, nk), cv = fetch_chunk(vbase, D, 0, nk);
+    // the streamed chunks are fetched APF chunks ahead (see APF)
+    ChunkRegs ck[APF], cv[APF];
+#pragma unroll
+    for (int p = 0; p < APF; ++p) {
+        ck[p] = ChunkRegs{}; cv[p] = ChunkRegs{};
+        if (p * CH < nk) { ck[p] = fetch_chunk(kbase, D, p * CH, nk); cv[p] = fetch_chunk(vbase, D, p * CH, nk); }
+    }
     for (int c0 = 0; c0 < nk; c0 += CH) {
         __syncthreads();
-        chunk_store<AR>(sK, ck);
-        chunk_store<AR>(sV, cv);
+        chunk_store<AR>(sK, ck[0]);
+        chunk_store<AR>(sV, cv[0]);
         __syncthreads();
-        if (c0 + CH < nk) { ck = fetch_chunk(kbase, D, c0 + CH, nk); cv = fetch_chunk(vbase, D, c0 + CH, nk); }
+#pragma unroll
+        for (int p = 0; p + 1 < APF; ++p) { ck[p] = ck[p + 1]; cv[p] = cv[p + 1]; }
+        if (c0 + APF * CH < nk) { ck[APF - 1] = fetch_chunk(kbase, D, c0 + APF * CH, nk); cv[APF - 1] = fetch_chunk(vbase, D, c0 + APF * CH, nk); }
         if (!wave_active) continue;
         f32x16 s[2];
         float cmax = -INFINITY;
@@ -333,18 +348,25 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     for (int e = 0; e < 16; ++e) { acc1[e] = 0.f; acc2[e] = 0.f; }
 
     const bool wave_active = blockIdx.x * COLS_PER_BLOCK + wave * 32 < ncol;
-    ChunkRegs c1 = fetch_chunk(r1base, D, 0, nrow), c2 = fetch_chunk(r2base, r2stride, 0, nrow);
+    ChunkRegs c1[APF], c2[APF];                      // (fetched APF chunks ahead: see attn_fwd_kernel)
+#pragma unroll
+    for (int p = 0; p < APF; ++p) {
+        c1[p] = ChunkRegs{}; c2[p] = ChunkRegs{};
+        if (p * CH < nrow) { c1[p] = fetch_chunk(r1base, D, p * CH, nrow); c2[p] = fetch_chunk(r2base, r2stride, p * CH, nrow); }
+    }
     for (int c0 = 0; c0 < nrow; c0 += CH) {
         __syncthreads();
-        chunk_store<AR>(sR1, c1);
-        chunk_store<AR>(sR2, c2);
+        chunk_store<AR>(sR1, c1[0]);
+        chunk_store<AR>(sR2, c2[0]);
         if (KCOL && threadIdx.x < CH) {
             const int qi = c0 + threadIdx.x;
             sL[threadIdx.x] = qi < nq ? lse[bh * nq + qi] : 0.f;
             sD[threadIdx.x] = qi < nq ? dvec[bh * nq + qi] : 0.f;
         }
         __syncthreads();
-        if (c0 + CH < nrow) { c1 = fetch_chunk(r1base, D, c0 + CH, nrow); c2 = fetch_chunk(r2base, r2stride, c0 + CH, nrow); }
+#pragma unroll
+        for (int p = 0; p + 1 < APF; ++p) { c1[p] = c1[p + 1]; c2[p] = c2[p + 1]; }
+        if (c0 + APF * CH < nrow) { c1[APF - 1] = fetch_chunk(r1base, D, c0 + APF * CH, nrow); c2[APF - 1] = fetch_chunk(r2base, r2stride, c0 + APF * CH, nrow); }
         if (!wave_active) continue;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
