@@ -49,6 +49,13 @@ constexpr int COLS_PER_BLOCK = 128;
 #endif
 constexpr int APF = BDETR_ATTN_PF;
 
+// exp() of the softmax as ONE v_exp_f32: the scores are kept in the log2 domain (scale * log2(e) folded into the one multiply they
+// need anyway).  expf() is a ~12-instruction sequence and the forward kernel evaluated it 32 times per lane and chunk: 40 VALU
+// instructions per MFMA, the kernel VALU-bound at 0.14 MFMA busy (PMC, round 4).  Relative error of 2^x' against e^x: the rounding of
+// x' = x * log2(e), |x| * 6e-8 - the arguments are <= 0 and anything below -87 is zero either way.
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+__device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
+
 __device__ __forceinline__ int crow(int e, int lh) { return (e & 3) + 8 * (e >> 2) + 4 * lh; }   // accumulator row of register e
 
 // rows [r0, r0+64) of a strided matrix -> two float4 per thread (rows >= n are zero-filled) -> LDS [64][ALD].
@@ -243,6 +250,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     for (int e = 0; e < 16; ++e) oacc[e] = 0.f;
     float m = -INFINITY, l = 0.f;
 
+    const float scale2 = scale * LOG2E;
     const bool wave_active = blockIdx.x * COLS_PER_BLOCK + wave * 32 < nq;      // wave-uniform: idle waves only help loading
     // the streamed chunks are fetched APF chunks ahead (see APF)
     ChunkRegs ck[APF], cv[APF];
@@ -262,24 +270,25 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
         if (!wave_active) continue;
         f32x16 s[2];
         float cmax = -INFINITY;
+        const bool full = c0 + CH <= nk;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             s[t] = rows_x_col<AR>(sK, t, qr, li, lh);              // S^T tile: rows = keys, column = this lane's query
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const float val = (c0 + 32 * t + crow(e, lh) < nk) ? s[t][e] * scale : -INFINITY;
+                const float val = (full || c0 + 32 * t + crow(e, lh) < nk) ? s[t][e] * scale2 : -INFINITY;      // log2 domain; `full`: no ragged rows in this chunk (uniform)
                 s[t][e] = val;
                 cmax = fmaxf(cmax, val);
             }
         }
         cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
         const float mn = fmaxf(m, cmax);
-        const float alpha = expf(m - mn);
+        const float alpha = exp2_fast(m - mn);
         float psum = 0.f;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { const float p = expf(s[t][e] - mn); s[t][e] = p; psum += p; }
+            for (int e = 0; e < 16; ++e) { const float p = exp2_fast(s[t][e] - mn); s[t][e] = p; psum += p; }
         psum += __shfl_xor(psum, 32, 64);
         l = l * alpha + psum;
         m = mn;
@@ -293,7 +302,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
         float* orow = o + (((int64_t)b * h + head) * nq + qi) * AD;
 #pragma unroll
         for (int e = 0; e < 16; ++e) orow[crow(e, lh)] = oacc[e] * inv;
-        if (lh == 0) lse[((int64_t)b * h + head) * nq + qi] = m + logf(l);
+        if (lh == 0) lse[((int64_t)b * h + head) * nq + qi] = m * LN2 + logf(l);          // (m is a log2-domain maximum)
     }
 }
 
@@ -341,7 +350,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     const int64_t r2stride = KCOL ? AD : D;
 
     float Lcol = 0.f, Dcol = 0.f;
-    if (!KCOL && cok) { Lcol = lse[bh * nq + ci]; Dcol = dvec[bh * nq + ci]; }
+    if (!KCOL && cok) { Lcol = lse[bh * nq + ci] * LOG2E; Dcol = dvec[bh * nq + ci]; }      // (log2 domain: see exp2_fast)
+    const float scale2 = scale * LOG2E;
 
     f32x16 acc1, acc2;
 #pragma unroll
@@ -360,7 +370,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
         chunk_store<AR>(sR2, c2[0]);
         if (KCOL && threadIdx.x < CH) {
             const int qi = c0 + threadIdx.x;
-            sL[threadIdx.x] = qi < nq ? lse[bh * nq + qi] : 0.f;
+            sL[threadIdx.x] = qi < nq ? lse[bh * nq + qi] * LOG2E : 0.f;
             sD[threadIdx.x] = qi < nq ? dvec[bh * nq + qi] : 0.f;
         }
         __syncthreads();
@@ -368,6 +378,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
         for (int p = 0; p + 1 < APF; ++p) { c1[p] = c1[p + 1]; c2[p] = c2[p + 1]; }
         if (c0 + APF * CH < nrow) { c1[APF - 1] = fetch_chunk(r1base, D, c0 + APF * CH, nrow); c2[APF - 1] = fetch_chunk(r2base, r2stride, c0 + APF * CH, nrow); }
         if (!wave_active) continue;
+        const bool full = c0 + CH <= nrow;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             f32x16 S = rows_x_col<AR>(sR1, t, c1r, li, lh);     // scores      (rows = streamed side)
@@ -376,7 +387,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
             for (int e = 0; e < 16; ++e) {
                 const int r = 32 * t + crow(e, lh);
                 const float Lq = KCOL ? sL[r] : Lcol, Dq = KCOL ? sD[r] : Dcol;
-                const float p = (c0 + r < nrow) ? expf(S[e] * scale - Lq) : 0.f;
+                const float p = (full || c0 + r < nrow) ? exp2_fast(S[e] * scale2 - Lq) : 0.f;
                 S[e] = p * (G[e] - Dq) * scale;                  // dS (gradient w.r.t. the unscaled product)
                 G[e] = p;
             }

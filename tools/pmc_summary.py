@@ -18,7 +18,7 @@ import json
 import os
 import sys
 
-KERNELS = ("hconv_kernel", "sgemm_kernel", "igemm_kernel", "rowchain_fwd_kernel", "rowchain_bwd_kernel", "hwgrad_kernel")
+KERNELS = ("hconv_kernel", "sgemm_kernel", "igemm_kernel", "rowchain_fwd_kernel", "rowchain_bwd_kernel", "hwgrad_kernel", "attn_fwd_kernel", "attn_bwd_kernel")
 
 
 def reduce_dirs(dirs):
