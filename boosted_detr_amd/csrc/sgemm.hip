@@ -1064,16 +1064,19 @@ extern "C" int bdetr_p16_conv2d_bwd_weight_splitk(const bdetr_conv_desc* d) {
     const int64_t Kd = (int64_t)d->R * d->S * d->C;
     const int t = wgrad_tile(d);
     const int64_t tiles = cdiv64(d->K, TILE_BM[t]) * cdiv64(Kd, TILE_BN[t]);
-    static int want_x = 0, min_stages = 0;
+    static int want_x = 0, want_3x3 = 0, min_stages = 0;
     if (want_x == 0) {
         const char* e = getenv("BDETR_WGRAD_WANT"); want_x = e ? atoi(e) : 2;      // measured: 2 workgroups per CU (5.9 ms over the ResNet-50 layers) beats 1 (6.5), 3 (6.4), 4 (6.9): atomic bytes grow with the split
+        const char* e3 = getenv("BDETR_WGRAD_WANT_3X3"); want_3x3 = e3 ? atoi(e3) : want_x;      // (the same for the im2col layers alone: A/B switch)
+        if (want_3x3 < 1) want_3x3 = 1;
         const char* f = getenv("BDETR_WGRAD_MINSTAGES"); min_stages = f ? atoi(f) : 8;
         if (want_x < 1) want_x = 1;
         if (min_stages < 1) min_stages = 1;
     }
     // floor, not ceil: all tiles x slices must fit the want_x * CUs resident slots at once - one workgroup more than
     // that runs alone in a second round and doubles the launch's duration
-    int64_t sk = ((int64_t)(t == T_PP256x128 ? 1 : want_x) * num_cus()) / tiles;       // (the ping-pong tile: one workgroup of eight waves per CU)
+    const int want = (d->R == 1 && d->S == 1) ? want_x : want_3x3;
+    int64_t sk = ((int64_t)(t == T_PP256x128 ? 1 : want) * num_cus()) / tiles;       // (the ping-pong tile: one workgroup of eight waves per CU)
     const int64_t maxsk = cdiv64(M, (int64_t)min_stages * BK);       // keep >= min_stages K-steps per split
     if (sk > maxsk) sk = maxsk;
     if (sk < 1) sk = 1;
