@@ -10,6 +10,15 @@ import sys
 import numpy as np
 import pytest
 
+def _free_port() -> str:
+    """A port nobody listens on right now (fixed numbers collided with other jobs sharing the box's network namespace: one abort in
+    RCCL's bootstrap in round 4)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return str(s.getsockname()[1])
+
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -83,7 +92,7 @@ dist.destroy_process_group()
 def test_two_replica_gradient_equivalence(cuda, tmp_path):
     script = tmp_path / "dp_worker.py"
     script.write_text(_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port(), WORLD_SIZE="2")
     procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=600)[0] for p in procs]
@@ -132,7 +141,7 @@ def test_two_replicas_config2_batch32_overlapped_allreduce(cuda, tmp_path):
     identical weights and the caching allocator must stay below 2x the live peak (no record_stream parking)."""
     script = tmp_path / "dp_cfg2.py"
     script.write_text(_WORKER_CFG2)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", WORLD_SIZE="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port(), WORLD_SIZE="2")
     procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=900)[0] for p in procs]
@@ -225,7 +234,7 @@ def test_rccl_branch_runs_on_a_one_rank_communicator(cuda, tmp_path):
     the collectives on although world_size is 1), through a freeze / unfreeze cycle with early bucket launches armed."""
     script = tmp_path / "rccl1.py"
     script.write_text(_WORKER_RCCL1)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29551", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", BDETR_DP_FORCE="1",
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port(), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", BDETR_DP_FORCE="1",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert p.returncode == 0 and "RCCL_ONE_RANK_OK" in p.stdout, p.stdout[-3000:]
@@ -236,11 +245,11 @@ def test_bench_multi_rank_code_path_over_one_rank_rccl(cuda):
     """bench.py's N > 1 branch (nccl init with device_id, distribute(), barriers, max-over-ranks timing, per-bucket all-reduce
     timing) on a one-rank RCCL communicator: the line must carry what the driver's 8-GPU run will be checked against."""
     import json
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29553", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", BDETR_DP_FORCE="1",
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port(), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", BDETR_DP_FORCE="1",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-roofline",
                         "--no-batch32", "--no-fp32-policy"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
-    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+    assert p.returncode == 0, (p.stdout[-2000:], "\n".join(l for l in p.stderr.splitlines() if not l.startswith("frame #"))[-6000:])
     line = json.loads(p.stdout.strip().splitlines()[-1])
     d = line["config"]["distributed"]
     assert d["backend"] == "nccl" and d["world_size"] == 1 and d["rccl_version"], d
@@ -301,7 +310,7 @@ def test_data_parallel_step_replays_as_hipgraphs_over_a_one_rank_rccl_communicat
     bit for bit."""
     script = tmp_path / "rccl_graph.py"
     script.write_text(_WORKER_RCCL_GRAPH)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29557", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", BDETR_DP_FORCE="1",
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port(), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", BDETR_DP_FORCE="1",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert p.returncode == 0 and "RCCL_GRAPH_DP_OK" in p.stdout, p.stdout[-3000:]

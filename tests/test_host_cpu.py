@@ -7,6 +7,15 @@ import sys
 import numpy as np
 import pytest
 
+def _free_port() -> str:
+    """A port nobody listens on right now (fixed numbers collided with other jobs sharing the box's network namespace: one abort in
+    RCCL's bootstrap in round 4)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return str(s.getsockname()[1])
+
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -188,7 +197,7 @@ def test_data_parallel_allreduce_gloo_world2(tmp_path):
     path uses with RCCL (bucketed async all-reduce of the flat gradient buffer + weight broadcast)."""
     script = tmp_path / "dp.py"
     script.write_text(_DP_SCRIPT)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port(), WORLD_SIZE="2")
     procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=240)[0] for p in procs]
