@@ -127,6 +127,9 @@ def test_bench_step_variants_are_all_oracle_tested(cuda, tmp_path):
             from test_p16_gpu import P16_BIG_CONVS, P16_CONVS, p16_conv_case
             for shp in P16_CONVS + P16_BIG_CONVS:              # the pre-split operand kernels (csrc/sgemm.hip)
                 p16_conv_case(*shp, accumulate=True)
+            from test_rowchain_gpu import test_rowchain_kernels_match_fp64 as rowchain_case      # the fused row chains (csrc/rowchain.hip)
+            for M_, stages in ((1600, 3), (98, 1)):
+                rowchain_case(None, M_, stages)
             tested = _prof_tuples(str(tmp_path / "tested.csv"))
         args = type("A", (), dict(model="detr", fashionpedia=False, backbone="ResNet", image=640, image_w=0, layers=6, queries=100,
                                   learners=3, batch=16))()
