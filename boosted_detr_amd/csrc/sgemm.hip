@@ -57,6 +57,7 @@ struct PPatch {
     const void* p; int N, H, W, C, OH, OW, R, S, stride, pad; int rows, cols;
     int d_ow, d_oh;                   // BK = d_oh * OW + d_ow: how far one K-step moves (oh, ow)
     unsigned k_step, k_wrap_ow, k_wrap_oh;
+    int single_wrap = 0;              // d_oh < OH: a K-step crosses at most one image boundary (XXPatch::advance without its loop)
 };
 
 // All byte offsets are uint32 with wrapping arithmetic: operands span < 4 GB, intermediate sums of a padding pixel
@@ -157,8 +158,16 @@ struct XXPatch {
     static __device__ __forceinline__ void advance(const Op& op, Col& c) {
         c.r += BK;
         c.ow += op.d_ow; c.oh += op.d_oh; c.iw += op.d_ow * op.stride; c.ih += op.d_oh * op.stride; c.off += op.k_step;
-        if (c.ow >= op.OW) { c.ow -= op.OW; c.oh += 1; c.iw -= op.OW * op.stride; c.ih += op.stride; c.off += op.k_wrap_ow; }
-        while (c.oh >= op.OH) { c.oh -= op.OH; c.ih -= op.OH * op.stride; c.off += op.k_wrap_oh; }      // next image (several on maps smaller than a K-step)
+        // Selects, not branches: the per-lane `if` + `while` compiled to an exec-mask region and an inner loop per load - 100 of the
+        // 146 VALU instructions and most of the 2 SALU instructions per MFMA of the 3x3 weight gradient's K-step (PMC, round 4)
+        const bool w = c.ow >= op.OW;
+        c.ow -= w ? op.OW : 0; c.oh += w ? 1 : 0; c.iw -= w ? op.OW * op.stride : 0; c.ih += w ? op.stride : 0; c.off += w ? op.k_wrap_ow : 0u;
+        if (op.single_wrap) {                          // (uniform)
+            const bool v = c.oh >= op.OH;
+            c.oh -= v ? op.OH : 0; c.ih -= v ? op.OH * op.stride : 0; c.off += v ? op.k_wrap_oh : 0u;
+        } else {
+            while (c.oh >= op.OH) { c.oh -= op.OH; c.ih -= op.OH * op.stride; c.off += op.k_wrap_oh; }      // next image (several on maps smaller than a K-step)
+        }
     }
 };
 
@@ -867,6 +876,7 @@ PPatch make_patch(const void* p, int N, int H, int W, int C, int OH, int OW, int
     o.k_step = (unsigned)(o.d_ow * stride + o.d_oh * stride * W) * c4;
     o.k_wrap_ow = (unsigned)(stride * W - OW * stride) * c4;                  // ow -= OW, oh += 1   (wrapping uint32)
     o.k_wrap_oh = (unsigned)(H * W - OH * stride * W) * c4;                    // oh -= OH, next image
+    o.single_wrap = o.d_oh < OH;
     return o;
 }
 bool is_1x1_dense(const bdetr_conv_desc* d) { return d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0; }

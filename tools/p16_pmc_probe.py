@@ -1,5 +1,5 @@
 """A few launches of ONE pre-split conv product for `rocprofv3 --pmc` (counters of sgemm_kernel on a fixed shape).
-Usage: python tools/p16_pmc_probe.py <fwd|dgrad|wgrad> H C K R [batch]   e.g.  fwd 40 256 256 3"""
+Usage: python tools/p16_pmc_probe.py <fwd|dgrad|wgrad|wgradf16> H C K R [batch]   e.g.  fwd 40 256 256 3"""
 import os
 import sys
 
@@ -20,7 +20,8 @@ xf, xb = k.p16_pack(x)
 wf, wt = k.p16_pack_conv_weights(w)
 _, dyb = k.p16_pack(dy, want_f16=False)
 fn = {"fwd": lambda: k.p16_conv2d_fwd(xf, wf, bias, g, 0, want_stats=True), "dgrad": lambda: k.p16_conv2d_bwd_data(dyb, wt, g),
-      "wgrad": lambda: k.p16_conv2d_bwd_weight(xb, dyb, g, dw=dw, prezeroed=True)}[which]
+      "wgrad": lambda: k.p16_conv2d_bwd_weight(xb, dyb, g, dw=dw, prezeroed=True),
+      "wgradf16": lambda: k.p16_conv2d_bwd_weight(xf, dyb, g, dw=dw, prezeroed=True, x_f16=True)}[which]      # x as the forward's f16 pair (the 1x1 layers of the step)
 for _ in range(6):
     fn()
 torch.cuda.synchronize()
