@@ -35,7 +35,8 @@ PEAK_16BIT_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: dense bf16/f16 MFM
 ARITH = {0: ("fp32 MFMA", PEAK_FP32_MFMA_TFLOPS), 1: ("split-bf16 (3 bf16 MFMA products)", PEAK_16BIT_MFMA_TFLOPS / 3),
          2: ("split-fp16 (3 f16 MFMA products)", PEAK_16BIT_MFMA_TFLOPS / 3),
          3: ("pre-split f16 pairs (3 f16 MFMA products, operands split by their producers)", PEAK_16BIT_MFMA_TFLOPS / 3),
-         4: ("pre-split bf16 pairs (3 bf16 MFMA products, operands split by their producers)", PEAK_16BIT_MFMA_TFLOPS / 3)}
+         4: ("pre-split bf16 pairs (3 bf16 MFMA products, operands split by their producers)", PEAK_16BIT_MFMA_TFLOPS / 3),
+         5: ("three-term bf16 split (6 bf16 MFMA products, fp32-grade)", PEAK_16BIT_MFMA_TFLOPS / 6)}
 GFLOP_PER_IMAGE = 201.7                # 3 x fwd - conv1 bwd-data at 640^2, 6+6, N=100
 
 
@@ -581,8 +582,12 @@ def main():
         fp32_line = policy_leg("fp32", None, "every conv/GEMM product exact fp32 (v_mfma_f32_32x32x2_f32)")
         # every product of the step at 2^-22 or better with the forward still on the 16-bit MFMA: the headline's forward (f16 pairs,
         # three products) and an exact-fp32 backward (the headline's gradient products are bf16 pairs, 2^-18)
-        grade_line = policy_leg("split", "fp32", "forward products split-fp16 (f16 pairs, 3 MFMA products, ~2^-22), gradient products exact fp32 "
-                                "(v_mfma_f32_32x32x2_f32): no product of the step below fp32 grade")
+        # (a) gradient products as three bf16 terms / six products on the 16-bit MFMA (~2^-22.5, fp32's exponent range: BDETR_GEMM_BF16X6);
+        # (b) gradient products on the exact-fp32 MFMA
+        grade_line = policy_leg("split", "bf16x6", "forward products split-fp16 (f16 pairs, 3 MFMA products, ~2^-22), gradient products three-term "
+                                "bf16 split (6 MFMA products, ~2^-22.5; attention core exact fp32): no product of the step below fp32 grade, all "
+                                "conv/GEMM products on the 16-bit MFMA")
+        grade_line["with_exact_fp32_backward"] = policy_leg("split", "fp32", "forward split-fp16, gradient products exact fp32 (v_mfma_f32_32x32x2_f32)")
     # BASELINE.json configs[2]: BoostedDETR (3 weak learners) with the Fashionpedia heads (46 categories / 294 attributes, attribute
     # weight 1) at batch 16, graph replay like the headline.  A second model in the same process (its own flat buffers and graph pools).
     c2 = None

@@ -456,7 +456,7 @@ extern "C" int bdetr_attention_bwd(const float* q, const float* k, const float* 
     hipLaunchKernelGGL(attn_dvec_kernel, dim3((unsigned)((rows * 8 + 255) / 256)), dim3(256), 0, st, o, d_o, dvec_ws, rows);
     // gradient products: split-bf16 (fp32 range) under every policy but BDETR_GEMM_FP32, like the conv / GEMM family
     const dim3 gq((nq + COLS_PER_BLOCK - 1) / COLS_PER_BLOCK, h, B), gk((nk + COLS_PER_BLOCK - 1) / COLS_PER_BLOCK, h, B);
-    if (!attn_split_enabled() || bdgemm::gemm_mode() == BDETR_GEMM_FP32) {
+    if (!attn_split_enabled() || bdgemm::gemm_mode() == BDETR_GEMM_FP32 || bdgemm::gemm_mode() == BDETR_GEMM_BF16X6) {      // (bf16x6: the fp32-grade policy)
         hipLaunchKernelGGL((attn_bwd_kernel<false, AR_FP32>), gq, dim3(256), 0, st, q, k, v, d_o, lse, dvec_ws, dq, (float*)nullptr, h, nq, nk, scale);
         hipLaunchKernelGGL((attn_bwd_kernel<true, AR_FP32>), gk, dim3(256), 0, st, q, k, v, d_o, lse, dvec_ws, dk, dv, h, nq, nk, scale);
     } else {

@@ -11,7 +11,7 @@ namespace bdgemm {
 
 enum { ST_STORE = 0, ST_ACCUM = 1, ST_ATOMIC = 2 };
 // arithmetic codes (profiling `kind` = arith * 10000 + ...): 0-2 are igemm.hip's, 3-4 sgemm.hip's
-enum { AR_FP32 = 0, AR_BF16X3 = 1, AR_FP16X3 = 2, AR_P16_F16 = 3, AR_P16_BF16 = 4 };
+enum { AR_FP32 = 0, AR_BF16X3 = 1, AR_FP16X3 = 2, AR_P16_F16 = 3, AR_P16_BF16 = 4, AR_BF16X6 = 5 };      // AR_BF16X6: three bf16 terms, six products (igemm.hip)
 
 struct GemmParams {
     int I, J, R;

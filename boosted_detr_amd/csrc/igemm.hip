@@ -44,7 +44,15 @@ constexpr int NTHREADS = 256;
 // subnormals for |x| < 0.25) and the two cross products accumulate in a second accumulator that is folded
 // in with 2^-11 in the epilogue.  Operand magnitudes must stay below 65504 (beyond that the hi half is
 // inf and the output NaN - loud, not silent); gradients, whose range is unbounded, never take this path.
+//
+// Three-term bf16 split ("bf16x6", round 4: the fp32-grade arithmetic ON the 16-bit MFMA): x = hi + mid + lo with three bf16 terms
+// (8 + 8 + 8 significant bits = fp32's 24) and a product keeps the six terms down to 2^-16 of it - hi*hi, hi*mid, mid*hi, hi*lo,
+// lo*hi, mid*mid; the dropped mid*lo, lo*mid, lo*lo are 2^-24 and below - six v_mfma_f32_32x32x16_bf16 per 16-deep step: ~2^-22.5
+// relative error per product at 6/16 of the fp32 MFMA's cycles, fp32's exponent range (so gradients may use it).  LDS rows grow a
+// third 16-dword plane: [16 hi | 16 mid (the two-term layout's lo position) | 16 lo | 4 pad] = 52 dwords (an odd multiple of 4 like
+// 36: the 16 rows of a ds_read_b128 pass still land in 16 distinct 4-bank groups).
 constexpr int SLD = 36;      // dwords per LDS row in split mode
+constexpr int SLD3 = 52;     // ... with three planes (bf16x6)
 constexpr float LO_SCALE = 2048.f;
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -67,6 +75,19 @@ __device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigne
         const f32x2 r = (v - __builtin_convertvector(h, f32x2)) * LO_SCALE;           // residual exact, then 2^11
         lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
     }
+}
+
+// three bf16 terms of two values (bf16x6): hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid); the residuals are exact in fp32
+__device__ __forceinline__ void split3(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
+    f32x2 v; v[0] = x0; v[1] = x1;
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+    f32x2 r;
+    r[0] = x0 - __builtin_bit_cast(float, hi << 16);
+    r[1] = x1 - __builtin_bit_cast(float, hi & 0xFFFF0000u);
+    mid = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+    r[0] -= __builtin_bit_cast(float, mid << 16);
+    r[1] -= __builtin_bit_cast(float, mid & 0xFFFF0000u);
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
 }
 
 // ----------------------------------------------------------------------------------------
@@ -189,8 +210,10 @@ void igemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
     static_assert(GA::NV >= 1 && GB::NV >= 1, "tile too small for 256 threads");
 
     constexpr bool SPLIT = ARITH != AR_FP32;
-    constexpr int A_FLOATS = SPLIT ? BM * SLD : GA::LDS_FLOATS;
-    constexpr int B_FLOATS = SPLIT ? BN * SLD : GB::LDS_FLOATS;
+    constexpr bool X6 = ARITH == AR_BF16X6;
+    constexpr int SLDK = X6 ? SLD3 : SLD;           // dwords per LDS row
+    constexpr int A_FLOATS = SPLIT ? BM * SLDK : GA::LDS_FLOATS;
+    constexpr int B_FLOATS = SPLIT ? BN * SLDK : GB::LDS_FLOATS;
     constexpr int STAGE_FLOATS = A_FLOATS + B_FLOATS;
     static_assert(!SPLIT || ((A_RC || GA::NV % 2 == 0) && (B_RC || GB::NV % 2 == 0)), "split mode transposes k-pairs");
     __shared__ __attribute__((aligned(16))) float lds[2 * STAGE_FLOATS];
@@ -262,12 +285,12 @@ void igemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
             const int q = v / vpr, c4 = v - q * vpr;             // vpr = 8: k = 4*c4 .. 4*c4+3
             const int rt = (q & ~15) | ((q & 3) << 2) | ((q >> 2) & 3);
             row = rt; col = 4 * c4;
-            ldsoff = rt * SLD * 32 + ((((c4 >> 1) ^ ((rt >> 4) & 7)) << 2) | ((c4 & 1) << 1));
+            ldsoff = rt * SLDK * 32 + ((((c4 >> 1) ^ ((rt >> 4) & 7)) << 2) | ((c4 & 1) << 1));
         } else {
             const int u = tid + NTHREADS * (p >> 1);
             const int kp = u / (bx / 4), c4 = u - kp * (bx / 4);
             row = 2 * kp + (p & 1); col = 4 * c4;
-            ldsoff = (4 * c4) * SLD * 32 + ((((kp >> 2) ^ ((c4 >> 2) & 7)) << 2) | (kp & 3));
+            ldsoff = (4 * c4) * SLDK * 32 + ((((kp >> 2) ^ ((c4 >> 2) & 7)) << 2) | (kp & 3));
         }
     };
 #pragma unroll
@@ -298,18 +321,30 @@ void igemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
     };
     auto write_split = [&](unsigned* base, bool rc, auto nv_c, const f32x4* r, const int* ldsoff) {
         constexpr int nv = decltype(nv_c)::value;
+        // (three planes: the third sits behind the 32 interleaved hi / mid dwords at the hi position's offset inside its 16-dword half)
         if (rc) {
 #pragma unroll
             for (int p = 0; p < nv; ++p) {
-                unsigned h0, l0, h1, l1;
-                split2<ARITH>(r[p][0], r[p][1], h0, l0);
-                split2<ARITH>(r[p][2], r[p][3], h1, l1);
-                u32x2 hi, lo;
-                hi[0] = h0; hi[1] = h1; lo[0] = l0; lo[1] = l1;
                 unsigned* row = base + (ldsoff[p] >> 5);
                 const int w = ldsoff[p] & 31;
-                *reinterpret_cast<u32x2*>(row + w) = hi;
-                *reinterpret_cast<u32x2*>(row + (w ^ 16)) = lo;
+                if constexpr (X6) {
+                    unsigned h0, m0, l0, h1, m1, l1;
+                    split3(r[p][0], r[p][1], h0, m0, l0);
+                    split3(r[p][2], r[p][3], h1, m1, l1);
+                    u32x2 hi, mid, lo;
+                    hi[0] = h0; hi[1] = h1; mid[0] = m0; mid[1] = m1; lo[0] = l0; lo[1] = l1;
+                    *reinterpret_cast<u32x2*>(row + w) = hi;
+                    *reinterpret_cast<u32x2*>(row + (w ^ 16)) = mid;
+                    *reinterpret_cast<u32x2*>(row + 32 + (w & 15)) = lo;
+                } else {
+                    unsigned h0, l0, h1, l1;
+                    split2<ARITH>(r[p][0], r[p][1], h0, l0);
+                    split2<ARITH>(r[p][2], r[p][3], h1, l1);
+                    u32x2 hi, lo;
+                    hi[0] = h0; hi[1] = h1; lo[0] = l0; lo[1] = l1;
+                    *reinterpret_cast<u32x2*>(row + w) = hi;
+                    *reinterpret_cast<u32x2*>(row + (w ^ 16)) = lo;
+                }
             }
         } else {
 #pragma unroll
@@ -318,10 +353,18 @@ void igemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
                 const int w = ldsoff[p] & 31;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    unsigned hi, lo;
-                    split2<ARITH>(r[p][e], r[p + 1][e], hi, lo);
-                    row[e * SLD + w] = hi;
-                    row[e * SLD + (w ^ 16)] = lo;
+                    if constexpr (X6) {
+                        unsigned hi, mid, lo;
+                        split3(r[p][e], r[p + 1][e], hi, mid, lo);
+                        row[e * SLDK + w] = hi;
+                        row[e * SLDK + (w ^ 16)] = mid;
+                        row[e * SLDK + 32 + (w & 15)] = lo;
+                    } else {
+                        unsigned hi, lo;
+                        split2<ARITH>(r[p][e], r[p + 1][e], hi, lo);
+                        row[e * SLDK + w] = hi;
+                        row[e * SLDK + (w ^ 16)] = lo;
+                    }
                 }
             }
         }
@@ -361,25 +404,38 @@ void igemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) {
                 u32x4 ah[TM], al[TM], bh[TN], bl[TN];
+                u32x4 a3[X6 ? TM : 1], b3[X6 ? TN : 1];      // bf16x6: al / bl hold the MID terms, a3 / b3 the third ones
 #pragma unroll
                 for (int a = 0; a < TM; ++a) {
                     const int xb = wm * WTM + a * 32 + li;
                     const int w = ((ks * 2 + lh) ^ ((xb >> 4) & 7)) << 2;
-                    ah[a] = *reinterpret_cast<const u32x4*>(qA + xb * SLD + w);
-                    al[a] = *reinterpret_cast<const u32x4*>(qA + xb * SLD + (w ^ 16));
+                    ah[a] = *reinterpret_cast<const u32x4*>(qA + xb * SLDK + w);
+                    al[a] = *reinterpret_cast<const u32x4*>(qA + xb * SLDK + (w ^ 16));
+                    if constexpr (X6) a3[a] = *reinterpret_cast<const u32x4*>(qA + xb * SLDK + 32 + (w & 15));
                 }
 #pragma unroll
                 for (int b = 0; b < TN; ++b) {
                     const int xb = wn * WTN + b * 32 + li;
                     const int w = ((ks * 2 + lh) ^ ((xb >> 4) & 7)) << 2;
-                    bh[b] = *reinterpret_cast<const u32x4*>(qB + xb * SLD + w);
-                    bl[b] = *reinterpret_cast<const u32x4*>(qB + xb * SLD + (w ^ 16));
+                    bh[b] = *reinterpret_cast<const u32x4*>(qB + xb * SLDK + w);
+                    bl[b] = *reinterpret_cast<const u32x4*>(qB + xb * SLDK + (w ^ 16));
+                    if constexpr (X6) b3[b] = *reinterpret_cast<const u32x4*>(qB + xb * SLDK + 32 + (w & 15));
                 }
 #pragma unroll
                 for (int a = 0; a < TM; ++a)
 #pragma unroll
                     for (int b = 0; b < TN; ++b) {
-                        if constexpr (ARITH == AR_BF16X3) {
+                        if constexpr (X6) {
+#define BF8(v) __builtin_bit_cast(bf16x8, v)
+                            // smallest terms first (2^-16: lo*hi, hi*lo, mid*mid; 2^-8: mid*hi, hi*mid; then hi*hi)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF8(a3[a]), BF8(bh[b]), acc[a][b], 0, 0, 0);
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF8(ah[a]), BF8(b3[b]), acc[a][b], 0, 0, 0);
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF8(al[a]), BF8(bl[b]), acc[a][b], 0, 0, 0);
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF8(al[a]), BF8(bh[b]), acc[a][b], 0, 0, 0);
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF8(ah[a]), BF8(bl[b]), acc[a][b], 0, 0, 0);
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF8(ah[a]), BF8(bh[b]), acc[a][b], 0, 0, 0);
+#undef BF8
+                        } else if constexpr (ARITH == AR_BF16X3) {
 #define BF8(v) __builtin_bit_cast(bf16x8, v)
                             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF8(al[a]), BF8(bh[b]), acc[a][b], 0, 0, 0);
                             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF8(ah[a]), BF8(bl[b]), acc[a][b], 0, 0, 0);
@@ -510,7 +566,7 @@ int gemm_mode() {
     if (g_gemm_mode < 0) {
         const char* e = getenv("BDETR_GEMM_PRECISION");
         g_gemm_mode = !e ? BDETR_GEMM_MIXED : (!strcmp(e, "fp32") || !strcmp(e, "f32")) ? BDETR_GEMM_FP32
-                    : !strcmp(e, "bf16x3") ? BDETR_GEMM_BF16X3 : !strcmp(e, "split") ? BDETR_GEMM_SPLIT : BDETR_GEMM_MIXED;
+                    : !strcmp(e, "bf16x3") ? BDETR_GEMM_BF16X3 : !strcmp(e, "split") ? BDETR_GEMM_SPLIT : !strcmp(e, "bf16x6") ? BDETR_GEMM_BF16X6 : BDETR_GEMM_MIXED;
     }
     return g_gemm_mode;
 }
@@ -521,6 +577,7 @@ int use_split(bool grad) {      // -> AR_* of one product
         case BDETR_GEMM_FP32:   return AR_FP32;
         case BDETR_GEMM_BF16X3: return AR_BF16X3;
         case BDETR_GEMM_SPLIT:  return grad ? AR_BF16X3 : AR_FP16X3;
+        case BDETR_GEMM_BF16X6: return AR_BF16X6;
         default:                return grad ? AR_BF16X3 : AR_FP32;
     }
 }
@@ -612,6 +669,11 @@ int launch_any(const typename LA::Op& a, const typename LB::Op& b, GemmParams g,
             if (t.bm == 128 && t.bn == 64)  return launch_cfg<128, 64, 2, 2, LA, A_RC, LB, B_RC, AR_BF16X3>(a, b, g, zdim, st);
             return launch_cfg<64, 64, 2, 2, LA, A_RC, LB, B_RC, AR_BF16X3>(a, b, g, zdim, st);
         }
+        if (arith == AR_BF16X6 && t.bn >= 64) {
+            // (no 128x128: two stages of three planes are 106 KB of LDS - one workgroup per CU)
+            if (t.bm == 128) return launch_cfg<128, 64, 2, 2, LA, A_RC, LB, B_RC, AR_BF16X6>(a, b, g, zdim, st);
+            return launch_cfg<64, 64, 2, 2, LA, A_RC, LB, B_RC, AR_BF16X6>(a, b, g, zdim, st);
+        }
         if constexpr (A_RC && B_RC) {
             if (arith == AR_FP16X3 && t.bn >= 64) {
                 if (t.bm == 128 && t.bn == 128) return launch_cfg<128, 128, 2, 2, LA, A_RC, LB, B_RC, AR_FP16X3>(a, b, g, zdim, st);
@@ -678,7 +740,7 @@ extern "C" int64_t bdetr_splitk_workspace_elems(int64_t I, int64_t J, int splitk
 extern "C" int bdetr_device_cus(void) { return num_cus(); }
 
 extern "C" int bdetr_set_gemm_precision(int mode) {
-    BDETR_CHECK_ARG(mode >= BDETR_GEMM_FP32 && mode <= BDETR_GEMM_SPLIT, "bdetr_set_gemm_precision: unknown mode %d", mode);
+    BDETR_CHECK_ARG(mode >= BDETR_GEMM_FP32 && mode <= BDETR_GEMM_BF16X6, "bdetr_set_gemm_precision: unknown mode %d", mode);
     bdgemm::g_gemm_mode = mode;
     return 0;
 }
@@ -721,7 +783,7 @@ static int prof_sum(int arith, double* total_ms, int64_t* launches, double* flop
 }
 extern "C" int bdetr_prof_read(double* total_ms, int64_t* launches, double* flops) { return prof_sum(-1, total_ms, launches, flops); }
 extern "C" int bdetr_prof_read_arith(int arith, double* total_ms, int64_t* launches, double* flops) {
-    BDETR_CHECK_ARG(arith >= AR_FP32 && arith <= AR_P16_BF16, "bdetr_prof_read_arith: arith must be 0 (fp32), 1 (bf16x3), 2 (fp16x3), 3 (pre-split f16) or 4 (pre-split bf16)");
+    BDETR_CHECK_ARG(arith >= AR_FP32 && arith <= AR_BF16X6, "bdetr_prof_read_arith: arith must be 0 (fp32), 1 (bf16x3), 2 (fp16x3), 3 (pre-split f16), 4 (pre-split bf16) or 5 (bf16x6)");
     return prof_sum(arith, total_ms, launches, flops);
 }
 

@@ -30,8 +30,8 @@ def set_launch_stream(handle: Optional[int]) -> Optional[int]:
     return prev
 
 
-GEMM_FP32, GEMM_BF16X3, GEMM_MIXED, GEMM_SPLIT = 0, 1, 2, 3
-_GEMM_MODES = {"fp32": GEMM_FP32, "bf16x3": GEMM_BF16X3, "mixed": GEMM_MIXED, "split": GEMM_SPLIT}
+GEMM_FP32, GEMM_BF16X3, GEMM_MIXED, GEMM_SPLIT, GEMM_BF16X6 = 0, 1, 2, 3, 4
+_GEMM_MODES = {"fp32": GEMM_FP32, "bf16x3": GEMM_BF16X3, "mixed": GEMM_MIXED, "split": GEMM_SPLIT, "bf16x6": GEMM_BF16X6}
 
 
 def set_gemm_precision(mode) -> int:

@@ -54,11 +54,16 @@ int         bdetr_stream_priority_range(int* least, int* greatest);
  *                     conv weights are packed as 2^8 w and the epilogue multiplies by 2^-8); only
  *                     igemm.hip's IN-KERNEL split (stem, neck, transformer Dense: operands without a
  *                     producer that could pre-scale them) still scales lo by 2^11 into a second accumulator.
- * The env variable BDETR_GEMM_PRECISION=fp32|bf16x3|mixed|split picks the initial value.
+ *  BDETR_GEMM_BF16X6  fp32-grade products ON the 16-bit MFMA with fp32's exponent range (round 4): every operand is split on the
+ *                     fly into THREE bf16 terms (8 + 8 + 8 significant bits) and a product keeps the six terms down to 2^-16 of
+ *                     it - six v_mfma_f32_32x32x16_bf16, ~2^-22.5 relative error per product.  Meant as the policy of a backward
+ *                     pass behind a BDETR_GEMM_SPLIT forward (Python: Model.train_grad_precision = "bf16x6"); the attention core
+ *                     runs exact fp32 under it.
+ * The env variable BDETR_GEMM_PRECISION=fp32|bf16x3|mixed|split|bf16x6 picks the initial value.
  * This policy is the library's ONE piece of mutable state (a mode word like a rounding mode, not data): it is thread-local,
  * so a host thread's launches are unaffected by another thread's policy, and every launch reads it once on the host at
  * enqueue time - kernels already enqueued (or captured into a hipGraph) keep the arithmetic they were enqueued with. */
-enum { BDETR_GEMM_FP32 = 0, BDETR_GEMM_BF16X3 = 1, BDETR_GEMM_MIXED = 2, BDETR_GEMM_SPLIT = 3 };
+enum { BDETR_GEMM_FP32 = 0, BDETR_GEMM_BF16X3 = 1, BDETR_GEMM_MIXED = 2, BDETR_GEMM_SPLIT = 3, BDETR_GEMM_BF16X6 = 4 };
 int         bdetr_set_gemm_precision(int mode);
 int         bdetr_get_gemm_precision(void);
 

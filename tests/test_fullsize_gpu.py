@@ -68,9 +68,11 @@ def test_config2_batch2_matches_oracle(cuda):
     g_split = {v.name: v.grad_numpy().astype(np.float64) for v in model.trainable_variables}
     model.replay_backward("fp32")
     g_fp32 = {v.name: v.grad_numpy().astype(np.float64) for v in model.trainable_variables}
+    model.replay_backward("bf16x6")            # three bf16 terms, six products: the fp32-grade arithmetic on the 16-bit MFMA
+    g_x6 = {v.name: v.grad_numpy().astype(np.float64) for v in model.trainable_variables}
     model._kept_tape = None
     gmax = max(np.abs(g).max() for g in g64.values())
-    rows = []
+    rows, rows6 = [], []
     for name, ref in g64.items():
         ref = np.asarray(ref, np.float64)
         if name not in g_split or np.abs(ref).max() < 1e-6 * gmax:
@@ -79,8 +81,13 @@ def test_config2_batch2_matches_oracle(cuda):
         e_s, e_f = np.linalg.norm(g_split[name].reshape(ref.shape) - ref) / nrm, np.linalg.norm(g_fp32[name].reshape(ref.shape) - ref) / nrm
         rows.append((e_s / max(e_f, 1e-12), e_s, e_f, name))
         assert e_s <= 2.0 * e_f + 1e-4, (name, e_s, e_f)
+        e_6 = np.linalg.norm(g_x6[name].reshape(ref.shape) - ref) / nrm
+        rows6.append((e_6 / max(e_f, 1e-12), e_6, e_f, name))
+        assert e_6 <= 1.5 * e_f + 2e-6, (name, e_6, e_f)      # bf16x6: indistinguishable from exact fp32 products
     rows.sort(reverse=True)
     assert len(rows) > 250, len(rows)
+    rows6.sort(reverse=True)
+    print(f"bf16x6 / fp32 policy: worst ratio {rows6[0][0]:.2f} ({rows6[0][3]}: {rows6[0][1]:.2e} vs {rows6[0][2]:.2e}), median {rows6[len(rows6) // 2][0]:.2f}")
     over = [r for r in rows if r[0] > 2.0]
     print(f"gradient error vs fp64, split / fp32 policy, {len(rows)} tensors: worst ratio {rows[0][0]:.2f} ({rows[0][3]}: {rows[0][1]:.2e} vs {rows[0][2]:.2e}), "
           f"median ratio {rows[len(rows) // 2][0]:.2f}; {len(over)} tensors above 2x, their largest split error {max([r[1] for r in over], default=0.0):.2e}; "

@@ -14,8 +14,8 @@ import torch.nn.functional as F
 from test_kernels_gpu import close, dev, rnd
 
 pytestmark = pytest.mark.gpu
-TOL = {"fp32": 2e-5, "bf16x3": 6e-5, "split": 6e-5}          # gradient products (and everything under bf16x3)
-TOL_FWD = {"fp32": 2e-5, "bf16x3": 6e-5, "split": 2e-5}      # forward products: split = fp16x3, fp32-grade
+TOL = {"fp32": 2e-5, "bf16x3": 6e-5, "split": 6e-5, "bf16x6": 2e-5}          # gradient products (and everything under bf16x3 / bf16x6)
+TOL_FWD = {"fp32": 2e-5, "bf16x3": 6e-5, "split": 2e-5, "bf16x6": 2e-5}      # forward products: split = fp16x3, fp32-grade; bf16x6 = three bf16 terms, six products, fp32-grade
 
 LINEARS = [(300, 256, 256), (6400, 256, 1024), (1600, 1024, 256), (130, 52, 48), (4000, 64, 64), (25600, 128, 512),
            (1600, 1024, 82), (1600, 256, 3), (1600, 256, 4)]          # the heads: unaligned 82- / 3-wide outputs, the narrow 128x32 tile
@@ -29,7 +29,7 @@ BIG_CONVS = [(8, 80, 80, 128, 128, 3, 1, 1), (16, 40, 40, 256, 256, 3, 1, 1), (1
              (4, 320, 320, 4, 64, 7, 2, 3)]
 
 
-@pytest.fixture(params=["fp32", "bf16x3", "split"])
+@pytest.fixture(params=["fp32", "bf16x3", "split", "bf16x6"])
 def mode(request, cuda):
     from boosted_detr_amd import kernels as k
     prev = k.set_gemm_precision(request.param)
@@ -49,6 +49,31 @@ def test_default_policy_is_mixed(cuda):
     ref_b = dy.double() @ w.double()
     e_bwd = (k.linear_bwd_data(dev(dy), dev(w)).cpu().double() - ref_b).norm() / ref_b.norm()
     assert e_fwd < 1.5e-6 and 1.5e-6 < e_bwd < 1e-5, (float(e_fwd), float(e_bwd))
+
+
+def test_three_term_bf16_products_are_fp32_grade(cuda):
+    """BDETR_GEMM_BF16X6 (x = hi + mid + lo in bf16, six products) on a long reduction, relative L2 error against fp64: within 1.5x
+    the exact-fp32 MFMA's own and well under the two-term split's 2^-18 - for the forward, backward-data and
+    weight-gradient flavours and for operands spread over 12 decades of magnitude (bf16 keeps fp32's exponent range)."""
+    from boosted_detr_amd import kernels as k
+    x, w, dy = rnd(512, 4096, seed=1), rnd(256, 4096, seed=2), rnd(512, 256, seed=3)
+    scale = 10.0 ** torch.linspace(-6, 6, 4096)
+    xs = x * scale                                       # columns from 1e-6 to 1e6
+    refs = {"fwd": x.double() @ w.double().T, "bwd": dy.double() @ w.double(), "wgrad": dy.double().T @ x.double(),
+            "wide": xs.double() @ (w / scale).double().T}
+    err = {}
+    for mode in ("fp32", "bf16x3", "bf16x6"):
+        prev = k.set_gemm_precision(mode)
+        try:
+            got = {"fwd": k.linear_fwd(dev(x), dev(w), None, 0), "bwd": k.linear_bwd_data(dev(dy), dev(w)), "wgrad": k.linear_bwd_weight(dev(dy), dev(x)),
+                   "wide": k.linear_fwd(dev(xs), dev(w / scale), None, 0)}
+        finally:
+            k.set_gemm_precision(prev)
+        err[mode] = {n: float((got[n].cpu().double() - refs[n]).norm() / refs[n].norm()) for n in refs}
+    print(err)
+    for n in refs:
+        assert err["bf16x6"][n] <= 1.5 * err["fp32"][n] + 1e-7, (n, err)
+        assert err["bf16x6"][n] < 0.5 * err["bf16x3"][n], (n, err)      # (measured 0.07-0.22: on the 4096-long sums the fp32 ACCUMULATION is what is left - 1.0e-6 against the fp32 MFMA's 1.1e-6)
 
 
 def linear_case(mode, M, K, O):

@@ -534,10 +534,12 @@ def test_replayed_step_is_bit_identical_with_the_runtime_packet_path_on(cuda):
         assert out[kind]["first_difference"] is None and out[kind]["first_nonfinite_or_flag_in_graph_run"] is None, (kind, out[kind])
 
 
-def test_gradient_policy_of_its_own_runs_the_backward_under_it(cuda, deterministic):
-    """Model.train_grad_precision = 'fp32' after the 'split' forward (bench.py's value_fp32_grade leg: no product of the step below
-    2^-22): the gradients ARE the ones replay_backward('fp32') computes from the same saved forward - bit for bit in deterministic
-    mode - and differ from the all-'split' step's; a captured step under that policy equals the eager one."""
+@pytest.mark.parametrize("grad_policy", ["fp32", "bf16x6"])
+def test_gradient_policy_of_its_own_runs_the_backward_under_it(cuda, deterministic, grad_policy):
+    """Model.train_grad_precision = 'bf16x6' (three bf16 terms, six products on the 16-bit MFMA) or 'fp32' after the 'split' forward
+    (bench.py's value_fp32_grade legs: no product of the step below 2^-22): the gradients ARE the ones replay_backward(policy)
+    computes from the same saved forward - bit for bit in deterministic mode - and differ from the all-'split' step's; a captured
+    step under that policy equals the eager one."""
     from boosted_detr_amd.engine import to_device
     from boosted_detr_amd.training import SGD
     from oracle import detr_oracle as O
@@ -551,10 +553,10 @@ def test_gradient_policy_of_its_own_runs_the_backward_under_it(cuda, determinist
     grads = lambda: {v.name: v.grad.detach().cpu().numpy().copy() for v in m.trainable_variables if v.grad is not None}
     m.forward_backward(batch)
     g_split = grads()
-    m.train_grad_precision = "fp32"
+    m.train_grad_precision = grad_policy
     m.forward_backward(batch, keep_tape=True)
     g_own = grads()
-    m.replay_backward("fp32")
+    m.replay_backward(grad_policy)
     g_replay = grads()
     m._kept_tape = None
     assert set(g_own) == set(g_replay) == set(g_split) and len(g_own) > 50
@@ -567,7 +569,7 @@ def test_gradient_policy_of_its_own_runs_the_backward_under_it(cuda, determinist
         mm.compile(optimizer=SGD(1e-3, momentum=.9, nesterov=True, clipnorm=.1))
         mm.forward_backward(batch)
         mm.set_weights_dict(O.make_params(cfg, seed=1))
-        mm.train_grad_precision, mm.use_graph = "fp32", graph
+        mm.train_grad_precision, mm.use_graph = grad_policy, graph
         losses = [mm.logs_to_host(mm.train_step(batch))["loss"] for _ in range(5)]
         assert (len(mm._graphs) == 1) == graph
         runs[graph] = (losses, mm.get_weights_dict())
