@@ -254,6 +254,14 @@ struct StatFn {
 // the BN affine map, written once with an explicit fma so that the forward (bn_apply) and the
 // backward's recomputed ReLU mask round identically
 __device__ __forceinline__ float bn_affine(float v, float m, float rs, float g, float b) { return __builtin_fmaf(v - m, rs * g, b); }
+// ... and BatchNorm's input gradient, (g - dbeta / rows - xhat * dgamma / rows) * rstd * gamma, with its fused multiply-adds spelled out:
+// the fp32 kernel, the P16 kernel (which hoists the per-channel terms out of its loop) and the stem's fused backward must round
+// identically whatever the compiler would contract in each of them (their tests compare with torch.equal)
+__device__ __forceinline__ float bn_bwd_dx(float g, float xv, float m, float rs, float gm, float dg, float db, float inv_rows) {
+    const float xh = (xv - m) * rs;
+    const float t = __builtin_fmaf(-db, inv_rows, g);
+    return __builtin_fmaf(-xh, dg * inv_rows, t) * (rs * gm);
+}
 
 // ReLU bit mask written by bn_apply_p16 (1 bit per element instead of re-reading a 4-byte-per-element tensor in both
 // backward passes): element e of float4 index i lives in word (i >> 6) * 4 + e, bit i & 63
@@ -350,8 +358,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             r = g * (rs * gm);
         } else {
             f32x4 dg = *reinterpret_cast<const f32x4*>(dgamma + c), db = *reinterpret_cast<const f32x4*>(dbeta + c);
-            f32x4 xh = (xv - m) * rs;
-            r = (g - db * inv_rows - xh * (dg * inv_rows)) * (rs * gm);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = bn_bwd_dx(g[e], xv[e], m[e], rs[e], gm[e], dg[e], db[e], inv_rows);
         }
         reinterpret_cast<f32x4*>(dx)[i] = r;
     }
@@ -475,7 +483,10 @@ __global__ __launch_bounds__(256) void stem_bwd_apply_kernel(const float* __rest
         const f32x4 dg = *reinterpret_cast<const f32x4*>(dgamma + c), db = *reinterpret_cast<const f32x4*>(dbeta + c);
         f32x4 xh;
         const f32x4 g = stem_pixel_grad(dpool, tap, s, (unsigned)(i / c4n), c, yv, m, rs, gm, bt, xh);
-        reinterpret_cast<f32x4*>(dy)[i] = (g - db * inv_rows - xh * (dg * inv_rows)) * (rs * gm);      // bn_bwd_apply_kernel's expression
+        f32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = bn_bwd_dx(g[e], yv[e], m[e], rs[e], gm[e], dg[e], db[e], inv_rows);      // bn_bwd_apply_kernel's expression
+        reinterpret_cast<f32x4*>(dy)[i] = r;
     }
 }
 
@@ -489,28 +500,30 @@ __global__ __launch_bounds__(256) void bn_apply_p16_kernel(const float* __restri
                                                            void* __restrict__ out_f16, void* __restrict__ out_bf16, unsigned long long* __restrict__ relu_mask,
                                                            int* __restrict__ overflow_flag, int64_t n4, int c4n) {
     // n4 is even and the stride is even: the two lanes of a pair (one 8-element group) always run together
-    auto body = [&](int64_t i, const f32x4 v) {
-        const int c = (int)(i % c4n) * 4;
-        const f32x4 m = *reinterpret_cast<const f32x4*>(mean + c), rs = *reinterpret_cast<const f32x4*>(rstd + c);
-        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c), b = *reinterpret_cast<const f32x4*>(beta + c);
+    struct Affine { f32x4 m, rs, g, b; };
+    auto affine_of = [&](const float* pm, const float* prs, const float* pg, const float* pb, int c) {
+        return Affine{*reinterpret_cast<const f32x4*>(pm + c), *reinterpret_cast<const f32x4*>(prs + c), *reinterpret_cast<const f32x4*>(pg + c), *reinterpret_cast<const f32x4*>(pb + c)};
+    };
+    // the residual's four values, decoded (f16 pair) or raw (fp32 / the shortcut's un-normalised convolution output)
+    auto load_res = [&](int64_t i) {
+        f32x4 r = {0.f, 0.f, 0.f, 0.f};
+        if (residual != nullptr) {
+            if (residual_p16 == 1) { float r4[4]; p16_load4_f16(residual, i, r4); r = f32x4{r4[0], r4[1], r4[2], r4[3]}; }
+            else r = reinterpret_cast<const f32x4*>(residual)[i];
+        }
+        return r;
+    };
+    auto body = [&](int64_t i, const f32x4 v, const f32x4 rv, const Affine& p, const Affine& p2) {
         f32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = bn_affine(v[e], m[e], rs[e], g[e], b[e]);
+        for (int e = 0; e < 4; ++e) o[e] = bn_affine(v[e], p.m[e], p.rs[e], p.g[e], p.b[e]);
         if (residual != nullptr) {
             if (residual_p16 == 2) {
                 // the projection shortcut's BatchNorm, applied here: same bn_affine, same fp32 add as the two-pass form
-                const f32x4 rv = reinterpret_cast<const f32x4*>(residual)[i];
-                const f32x4 m2 = *reinterpret_cast<const f32x4*>(rbn.mean + c), rs2 = *reinterpret_cast<const f32x4*>(rbn.rstd + c);
-                const f32x4 g2 = *reinterpret_cast<const f32x4*>(rbn.gamma + c), b2 = *reinterpret_cast<const f32x4*>(rbn.beta + c);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] += bn_affine(rv[e], m2[e], rs2[e], g2[e], b2[e]);
-            } else if (residual_p16) {
-                float r4[4];
-                p16_load4_f16(residual, i, r4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] += r4[e];
+                for (int e = 0; e < 4; ++e) o[e] += bn_affine(rv[e], p2.m[e], p2.rs[e], p2.g[e], p2.b[e]);
             } else {
-                o += reinterpret_cast<const f32x4*>(residual)[i];
+                o += rv;
             }
         }
         if (relu) {
@@ -535,16 +548,36 @@ __global__ __launch_bounds__(256) void bn_apply_p16_kernel(const float* __restri
         }
         if (out_bf16 != nullptr) p16_store4<false>(out_bf16, i, o[0], o[1], o[2], o[3]);
     };
-    // Two row groups per trip with both x loads issued first (twice the bytes in flight per wave).  The trip count is decided
-    // per aligned 64-index group = per wave, so that the __ballot of a group always sees all of its lanes together.
+    // Two row groups per trip with EVERY load of the trip issued first: both x groups and both residual groups.  The per-channel
+    // parameters are loaded once per thread when the grid stride is a multiple of the channel count (the launch makes it one: a thread's
+    // channel then never changes).  Round 4: the loop used to reload the parameters per group and wait for each residual load on the spot
+    // - five dependent round trips per trip (ISA) - and ran at 4.2-4.7 TB/s on the residual forms against 5.3 for a plain copy.
+    // The trip count is decided per aligned 64-index group = per wave, so that the __ballot of a group always sees all of its lanes together.
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; (i | 63) + stride < n4; i += 2 * stride) {
-        const f32x4 v0 = reinterpret_cast<const f32x4*>(x)[i], v1 = reinterpret_cast<const f32x4*>(x)[i + stride];
-        body(i, v0);
-        body(i + stride, v1);
+    const bool fixed_c = stride % c4n == 0;                    // (uniform)
+    const bool rb = residual != nullptr && residual_p16 == 2;
+    if (fixed_c) {
+        const int c = (int)(i % c4n) * 4;
+        const Affine p = affine_of(mean, rstd, gamma, beta, c);
+        const Affine p2 = rb ? affine_of(rbn.mean, rbn.rstd, rbn.gamma, rbn.beta, c) : p;
+        for (; (i | 63) + stride < n4; i += 2 * stride) {
+            const f32x4 v0 = reinterpret_cast<const f32x4*>(x)[i], v1 = reinterpret_cast<const f32x4*>(x)[i + stride];
+            const f32x4 r0 = load_res(i), r1 = load_res(i + stride);
+            body(i, v0, r0, p, p2);
+            body(i + stride, v1, r1, p, p2);
+        }
+        for (; i < n4; i += stride) { const f32x4 v0 = reinterpret_cast<const f32x4*>(x)[i]; const f32x4 r0 = load_res(i); body(i, v0, r0, p, p2); }
+        return;
     }
-    for (; i < n4; i += stride) body(i, reinterpret_cast<const f32x4*>(x)[i]);
+    for (; i < n4; i += stride) {
+        const int c = (int)(i % c4n) * 4;
+        const Affine p = affine_of(mean, rstd, gamma, beta, c);
+        const Affine p2 = rb ? affine_of(rbn.mean, rbn.rstd, rbn.gamma, rbn.beta, c) : p;
+        const f32x4 v0 = reinterpret_cast<const f32x4*>(x)[i];
+        const f32x4 r0 = load_res(i);
+        body(i, v0, r0, p, p2);
+    }
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_p16_kernel(const float* __restrict__ dout, const void* __restrict__ out, int out_p16, const float* __restrict__ x,
@@ -553,41 +586,69 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_p16_kernel(const float* __re
                                                                const float* __restrict__ dgamma, const float* __restrict__ dbeta, int relu, int frozen,
                                                                float* __restrict__ dx32, void* __restrict__ dx_bf16, float* __restrict__ dres,
                                                                int64_t n4, int c4n, float inv_rows) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % c4n) * 4;
-        f32x4 g = reinterpret_cast<const f32x4*>(dout)[i];
-        const f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + c), gm = *reinterpret_cast<const f32x4*>(gamma + c);
-        const f32x4 m = *reinterpret_cast<const f32x4*>(mean + c);
-        f32x4 xv = {0.f, 0.f, 0.f, 0.f};
-        const bool recompute = relu && out == nullptr;
-        if (!frozen || recompute) xv = reinterpret_cast<const f32x4*>(x)[i];
+    // Same shape as bn_apply_p16_kernel: per-channel terms once per thread when the grid stride is a multiple of the channel count, two
+    // row groups per trip with all their loads issued first.  The arithmetic is the unhoisted kernel's, operation for operation.
+    const bool recompute = relu && out == nullptr;
+    const bool need_x = !frozen || recompute;
+    struct Chan { f32x4 m, rs, gm, bt, dg, db; };
+    auto chan_of = [&](int c) {
+        Chan p;
+        p.rs = *reinterpret_cast<const f32x4*>(rstd + c); p.gm = *reinterpret_cast<const f32x4*>(gamma + c); p.m = *reinterpret_cast<const f32x4*>(mean + c);
+        p.bt = recompute ? *reinterpret_cast<const f32x4*>(beta + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        p.dg = f32x4{0.f, 0.f, 0.f, 0.f}; p.db = p.dg;
+        if (!frozen) { p.dg = *reinterpret_cast<const f32x4*>(dgamma + c); p.db = *reinterpret_cast<const f32x4*>(dbeta + c); }
+        return p;
+    };
+    struct In { f32x4 g, xv, o; unsigned pm; };
+    auto load_in = [&](int64_t i) {
+        In q;
+        q.g = reinterpret_cast<const f32x4*>(dout)[i];
+        q.xv = need_x ? reinterpret_cast<const f32x4*>(x)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        q.o = f32x4{0.f, 0.f, 0.f, 0.f}; q.pm = 0u;
+        if (relu && !recompute) {
+            if (out_p16) q.pm = out_p16 == 2 ? relu_mask_bits4(out, i) : p16_positive4_bf16(out, i);
+            else q.o = reinterpret_cast<const f32x4*>(out)[i];
+        }
+        return q;
+    };
+    auto body = [&](int64_t i, const In& q, const Chan& p) {
+        f32x4 g = q.g;
         if (relu) {
             if (!recompute && out_p16) {
-                const unsigned pm = out_p16 == 2 ? relu_mask_bits4(out, i) : p16_positive4_bf16(out, i);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) if (!((pm >> e) & 1u)) g[e] = 0.f;
+                for (int e = 0; e < 4; ++e) if (!((q.pm >> e) & 1u)) g[e] = 0.f;
             } else if (!recompute) {
-                const f32x4 o = reinterpret_cast<const f32x4*>(out)[i];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) if (!(o[e] > 0.f)) g[e] = 0.f;
+                for (int e = 0; e < 4; ++e) if (!(q.o[e] > 0.f)) g[e] = 0.f;
             } else {
-                const f32x4 bt = *reinterpret_cast<const f32x4*>(beta + c);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) if (!(bn_affine(xv[e], m[e], rs[e], gm[e], bt[e]) > 0.f)) g[e] = 0.f;
+                for (int e = 0; e < 4; ++e) if (!(bn_affine(q.xv[e], p.m[e], p.rs[e], p.gm[e], p.bt[e]) > 0.f)) g[e] = 0.f;
             }
         }
         if (dres != nullptr) reinterpret_cast<f32x4*>(dres)[i] = g;
         f32x4 r;
         if (frozen) {
-            r = g * (rs * gm);
+            r = g * (p.rs * p.gm);
         } else {
-            const f32x4 dg = *reinterpret_cast<const f32x4*>(dgamma + c), db = *reinterpret_cast<const f32x4*>(dbeta + c);
-            const f32x4 xh = (xv - m) * rs;
-            r = (g - db * inv_rows - xh * (dg * inv_rows)) * (rs * gm);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = bn_bwd_dx(g[e], q.xv[e], p.m[e], p.rs[e], p.gm[e], p.dg[e], p.db[e], inv_rows);
         }
         if (dx32 != nullptr) reinterpret_cast<f32x4*>(dx32)[i] = r;
         p16_store4<false>(dx_bf16, i, r[0], r[1], r[2], r[3]);
+    };
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (stride % c4n == 0) {                                   // (uniform)
+        const Chan p = chan_of((int)(i % c4n) * 4);
+        for (; i + stride < n4; i += 2 * stride) {            // (n4 and the stride are even: the two lanes of a pair share every trip)
+            const In q0 = load_in(i), q1 = load_in(i + stride);
+            body(i, q0, p);
+            body(i + stride, q1, p);
+        }
+        if (i < n4) body(i, load_in(i), p);
+        return;
     }
+    for (; i < n4; i += stride) body(i, load_in(i), chan_of((int)(i % c4n) * 4));
 }
 
 // ------------------------------------------------------------------------------------
@@ -900,6 +961,18 @@ extern "C" int bdetr_stem_pool_bwd(const float* dpool, const uint8_t* tap, const
     return bdetr_launch_status("stem_pool_bwd");
 }
 
+// element-wise grid whose stride (256 threads per workgroup) is a multiple of the channel-group count C / 4 where that costs at most a
+// few extra workgroups: a thread then keeps one channel group for the whole launch and loads its per-channel terms once
+// (bn_apply_p16_kernel, bn_bwd_apply_p16_kernel)
+static int channel_aligned_grid(int64_t n4, int C) {
+    int grid = ew_grid(n4, 256, 2);
+    int a = C / 4, b = 256;
+    while (b) { const int t = a % b; a = b; b = t; }              // a = gcd(C / 4, 256)
+    const int mult = (C / 4) / a;
+    if (mult > 1 && mult <= 8) grid = (grid + mult - 1) / mult * mult;
+    return grid;
+}
+
 extern "C" int bdetr_bn_apply_p16(const float* x, const float* mean, const float* rstd, const float* gamma,
                                   const float* beta, const void* residual, int residual_p16, const bdetr_bn_affine* residual_bn, int relu,
                                   float* out32, void* out_f16, void* out_bf16,
@@ -910,7 +983,8 @@ extern "C" int bdetr_bn_apply_p16(const float* x, const float* mean, const float
                     "bdetr_bn_apply_p16: residual_p16 = 2 needs the raw shortcut tensor and its BatchNorm");
     const bdetr_bn_affine rbn = residual_p16 == 2 ? *residual_bn : bdetr_bn_affine{nullptr, nullptr, nullptr, nullptr};
     const int64_t n4 = rows * C / 4;
-    hipLaunchKernelGGL(bn_apply_p16_kernel, dim3(ew_grid(n4, 256, 2)), dim3(256), 0, (hipStream_t)stream, x, mean, rstd, gamma, beta, residual, residual_p16, rbn, relu,
+    const int grid = channel_aligned_grid(n4, C);
+    hipLaunchKernelGGL(bn_apply_p16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, mean, rstd, gamma, beta, residual, residual_p16, rbn, relu,
                        out32, out_f16, out_bf16, reinterpret_cast<unsigned long long*>(relu_mask), overflow_flag, n4, C / 4);
     return bdetr_launch_status("bn_apply_p16");
 }
@@ -963,7 +1037,7 @@ static int bn_bwd_p16_impl(const float* dout, const void* out, int out_p16, cons
         sum_partials2(pa, pb, nch, C, dbeta, dgamma, st);
     }
     const int64_t n4 = rows * C / 4;
-    hipLaunchKernelGGL(bn_bwd_apply_p16_kernel, dim3(ew_grid(n4, 256, 2)), dim3(256), 0, st, dout, out, out_p16, x, mean, rstd, gamma, beta, dgamma, dbeta,
+    hipLaunchKernelGGL(bn_bwd_apply_p16_kernel, dim3(channel_aligned_grid(n4, C)), dim3(256), 0, st, dout, out, out_p16, x, mean, rstd, gamma, beta, dgamma, dbeta,
                        relu, frozen, dx32, dx_bf16, dresidual, n4, C / 4, 1.0f / (float)rows);
     return bdetr_launch_status("bn_bwd_p16");
 }
