@@ -475,18 +475,29 @@ __global__ __launch_bounds__(256) void stem_bwd_apply_kernel(const float* __rest
                                                              const float* __restrict__ beta, const float* __restrict__ dgamma, const float* __restrict__ dbeta,
                                                              StemGeom s, float* __restrict__ dy, int64_t n4, float inv_rows) {
     const int c4n = s.C / 4;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % c4n) * 4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    auto one = [&](int64_t i, int c, const f32x4 m, const f32x4 rs, const f32x4 gm, const f32x4 bt, const f32x4 dg, const f32x4 db) {
         const f32x4 yv = reinterpret_cast<const f32x4*>(y)[i];
-        const f32x4 m = *reinterpret_cast<const f32x4*>(mean + c), rs = *reinterpret_cast<const f32x4*>(rstd + c);
-        const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c), bt = *reinterpret_cast<const f32x4*>(beta + c);
-        const f32x4 dg = *reinterpret_cast<const f32x4*>(dgamma + c), db = *reinterpret_cast<const f32x4*>(dbeta + c);
         f32x4 xh;
         const f32x4 g = stem_pixel_grad(dpool, tap, s, (unsigned)(i / c4n), c, yv, m, rs, gm, bt, xh);
         f32x4 r;
 #pragma unroll
         for (int e = 0; e < 4; ++e) r[e] = bn_bwd_dx(g[e], yv[e], m[e], rs[e], gm[e], dg[e], db[e], inv_rows);      // bn_bwd_apply_kernel's expression
         reinterpret_cast<f32x4*>(dy)[i] = r;
+    };
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (stride % c4n == 0) {                                   // (uniform; always for the stem's 64 channels: a thread keeps its channel group)
+        const int c = (int)(i % c4n) * 4;
+        const f32x4 m = *reinterpret_cast<const f32x4*>(mean + c), rs = *reinterpret_cast<const f32x4*>(rstd + c);
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c), bt = *reinterpret_cast<const f32x4*>(beta + c);
+        const f32x4 dg = *reinterpret_cast<const f32x4*>(dgamma + c), db = *reinterpret_cast<const f32x4*>(dbeta + c);
+        for (; i < n4; i += stride) one(i, c, m, rs, gm, bt, dg, db);
+        return;
+    }
+    for (; i < n4; i += stride) {
+        const int c = (int)(i % c4n) * 4;
+        one(i, c, *reinterpret_cast<const f32x4*>(mean + c), *reinterpret_cast<const f32x4*>(rstd + c), *reinterpret_cast<const f32x4*>(gamma + c),
+            *reinterpret_cast<const f32x4*>(beta + c), *reinterpret_cast<const f32x4*>(dgamma + c), *reinterpret_cast<const f32x4*>(dbeta + c));
     }
 }
 
