@@ -161,7 +161,7 @@ def step_hbm(ms_per_step):
 ENV_REFUSED = ("BDETR_SGEMM_DBG", "BDETR_GRAPH_UNSAFE")
 ENV_RECORDED = ("BDETR_STILE", "BDETR_TILE", "BDETR_P16", "BDETR_BN_FUSE", "BDETR_LAZY_SKIP", "BDETR_WGRAD_WANT", "BDETR_WGRAD_MINSTAGES",
                 "BDETR_GEMM_PRECISION", "BDETR_SIDE_STREAM", "BDETR_SIDE_PRIORITY", "BDETR_GRAPH", "BDETR_DP_OVERLAP", "BDETR_DP_FORCE", "BDETR_LIB",
-                "BDETR_CXXFLAGS", "BDETR_FORCE_DEVICE", "BDETR_DIST_BACKEND", "BDETR_CPU_THREADS", "BDETR_HCONV", "BDETR_ATTN_SPLIT", "BDETR_WGRAD_XF16", "BDETR_BF16_3X3", "BDETR_WGRAD_1X1_TILE", "BDETR_GRAPH_SEG", "BDETR_GRAPH_SIDE", "BDETR_DETERMINISTIC", "BDETR_ROWCHAIN", "BDETR_ZERO_MEMSET", "BDETR_DP_GRAPH", "BDETR_HWGRAD", "BDETR_BN_FUSE2", "BDETR_HCONV_TILE", "BDETR_STEM_FUSE", "BDETR_BN_WIDE_REDUCE", "BDETR_EVEN_PIXELS", "BDETR_WGRAD_PP", "BDETR_WGRAD_WANT_3X3")
+                "BDETR_CXXFLAGS", "BDETR_FORCE_DEVICE", "BDETR_DIST_BACKEND", "BDETR_CPU_THREADS", "BDETR_HCONV", "BDETR_ATTN_SPLIT", "BDETR_WGRAD_XF16", "BDETR_BF16_3X3", "BDETR_WGRAD_1X1_TILE", "BDETR_GRAPH_SEG", "BDETR_GRAPH_SIDE", "BDETR_DETERMINISTIC", "BDETR_ROWCHAIN", "BDETR_ZERO_MEMSET", "BDETR_DP_GRAPH", "BDETR_HWGRAD", "BDETR_BN_FUSE2", "BDETR_HCONV_TILE", "BDETR_STEM_FUSE", "BDETR_BN_WIDE_REDUCE", "BDETR_EVEN_PIXELS", "BDETR_WGRAD_PP", "BDETR_WGRAD_WANT_3X3", "BDETR_LAUNCH_PROBE")
 
 
 def env_overrides() -> dict:
@@ -290,7 +290,8 @@ def main():
     ap.add_argument("--no-fp32-policy", action="store_true", help="skip the secondary measurement under the exact-fp32 arithmetic policy")
     ap.add_argument("--no-batch32", action="store_true", help="skip the secondary measurement at configs[3]'s per-GPU batch (32)")
     ap.add_argument("--no-configs2", action="store_true", help="skip the secondary measurement of configs[2] (BoostedDETR + Fashionpedia heads, batch 16)")
-    ap.add_argument("--graph", action="store_true", help="(default at N=1) replay the step as captured hipGraph segments (Model.use_graph) instead of enqueuing it from Python")
+    ap.add_argument("--graph", action="store_true", help="replay the step as captured hipGraph segments (Model.use_graph) whatever the launch probe would say (default: capture, then a "
+                    "10-step probe of replay against eager enqueue picks the faster for the timed steps)")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every step from Python (the N>1 runs always do: the collectives are issued from the backward pass)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -398,6 +399,41 @@ def main():
             note(f"set-up step {i} ({'captured' if model._graphs else 'eager'}): {(time.perf_counter() - tw) * 1e3:.1f} ms")
             if model._graphs:
                 break
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # Launch mode of the timed steps.  Replaying the captured chain of hipGraphs and enqueuing every launch from Python run the SAME
+    # kernels; which is faster depends on the host (round 4: at 1,017 launches per step a fast host enqueues ahead of the GPU and the finer
+    # side-stream overlap of the eager step wins by ~1 %; a slow or contended host loses several per cent without the replay).  Unless
+    # --graph / --no-graph decide, a short probe does: P steps each way behind their own warm-up, max over ranks, the decision is the same
+    # on every rank (it is taken from all-reduced times).  The probe is set-up: outside the W warm-up and K timed steps.
+    launch_probe = None
+    if model.use_graph and model._graphs and not args.graph and os.environ.get("BDETR_LAUNCH_PROBE", "1") != "0":
+        def probe(n):
+            barrier()
+            tp = time.perf_counter()
+            for _ in range(n):
+                run_step(batch)
+            barrier()
+            dt = time.perf_counter() - tp
+            if dist is not None:
+                t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            return dt / n * 1e3
+        P = 10
+        run_step(batch)
+        g_ms = probe(P)
+        model.use_graph = False
+        for _ in range(3):
+            run_step(batch)
+        e_ms = probe(P)
+        model.use_graph = not (e_ms < 0.995 * g_ms)            # eager only when it is clearly ahead
+        launch_probe = {"steps_each": P, "graph_replay_ms_per_step": round(g_ms, 3), "eager_ms_per_step": round(e_ms, 3),
+                        "chosen": "hipGraph replay" if model.use_graph else "eager"}
+        note(f"launch probe: replay {g_ms:.2f} ms/step, eager {e_ms:.2f} ms/step -> {launch_probe['chosen']}")
     for i in range(max(args.warmup, 1)):
         tw = time.perf_counter()
         run_step(batch)
@@ -407,11 +443,6 @@ def main():
         model._dp.broadcast_variables(model.variables)
     model.guard_flush()
     redos_before = model.range_redos
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     want_roof = not args.no_roofline          # every rank runs the bracketed region (collectives must match); rank 0 records
 
@@ -431,9 +462,11 @@ def main():
                     "check": "the flag is logged to pinned memory by the last kernel of every step and examined 2 steps later (Model._guard_poll)"}
 
     elapsed, guard = timed_region()
-    step_launch = "hipGraph replay (segmented)" if model._graphs else ("eager (graph replay refused: BDETR_ZERO_MEMSET=1 without "
-                                                                        "DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in force)" if graph_refused else "eager")
-    if model._graphs and (guard["range_redos_in_timed_region"] or guard["overflow_flag_after_run"]):
+    replayed = bool(model.use_graph and model._graphs)
+    step_launch = "hipGraph replay (segmented)" if replayed else ("eager (graph replay refused: BDETR_ZERO_MEMSET=1 without "
+                                                                   "DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in force)" if graph_refused else
+                                                                   "eager (faster than the replay in the launch probe)" if launch_probe else "eager")
+    if replayed and (guard["range_redos_in_timed_region"] or guard["overflow_flag_after_run"]):
         # A guard event under graph replay on a synthetic batch that trains cleanly when enqueued eagerly points at the replay, not at
         # the data.  Round 3 re-timed the eager step here; a line measured on a path that just misbehaved is not a
         # result, so this is an error now.
@@ -642,7 +675,7 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": dtype_note(model), "arithmetic": arithmetic_note(model), "data": "synthetic",
             "config": {"workload": workload_name(args), "per_gpu_batch": args.batch, "global_batch": global_batch,
-                       "parallelism": f"dp{world}", "step_launch": step_launch, "graph_capture_fallback": graph_fallback,
+                       "parallelism": f"dp{world}", "step_launch": step_launch, "launch_probe": launch_probe, "graph_capture_fallback": graph_fallback,
                        "runtime_switches": {"DEBUG_CLR_GRAPH_PACKET_CAPTURE": os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE"),
                                             "packet_capture_off_in_force": boosted_detr_amd.packet_capture_off(),
                                             "zero_fill": "hipMemset nodes" if os.environ.get("BDETR_ZERO_MEMSET") == "1" else "library kernel (no memset nodes in the captured step)"}, "gflop_per_image_algorithmic": gflop_img,

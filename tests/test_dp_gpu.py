@@ -248,7 +248,7 @@ def test_bench_multi_rank_code_path_over_one_rank_rccl(cuda):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port(), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", BDETR_DP_FORCE="1",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-roofline",
-                        "--no-batch32", "--no-fp32-policy"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+                        "--no-batch32", "--no-fp32-policy", "--graph"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert p.returncode == 0, (p.stdout[-2000:], "\n".join(l for l in p.stderr.splitlines() if not l.startswith("frame #"))[-6000:])
     line = json.loads(p.stdout.strip().splitlines()[-1])
     d = line["config"]["distributed"]
