@@ -17,9 +17,11 @@
 // Layout.  TRANSPOSED products: the MFMA's rows are output FEATURES (A operand = the weight tile), its columns are TOKENS (B
 // operand = the activations), so that the accumulator of one stage - a lane owns ONE token and 16 features per 32-feature tile -
 // has the LayerNorm axis inside the lane (+ one cross-wave exchange) and goes back to LDS as the next stage's B operand without a
-// transpose.  Wave w of the 4 owns features [64 w, 64 w + 64).  Weights never touch LDS: every wave reads a DIFFERENT quarter of a
+// transpose.  Wave w of the 8 owns features [32 w, 32 w + 32) (one 32-feature tile; -DBDETR_RC_WAVES=4: two tiles per wave, the
+// first form of the kernel - 256 VGPRs and AGPR spills; eight waves need 190-211 and measured +0.6-0.7 % on the step with any
+// look-ahead depth from 4 to 8, round 4).  Weights never touch LDS: every wave reads a DIFFERENT eighth of a
 // matrix, pre-packed in fragment order ([tile][k-step][hi | lo][lane] x 16 bytes: one fully coalesced 1-KiB load per fragment),
-// prefetched four k-steps ahead across stage boundaries (weights do not depend on data).  What bounds a stage is the 256 KB of
+// prefetched PF (8) k-steps ahead across stage boundaries (weights do not depend on data).  What bounds a stage is the 256 KB of
 // weights each workgroup streams from L2 (~70 GB/s per CU): ~3.7 us per stage, not the 96 MFMAs per wave.
 #include "gemm_common.h"
 #include "p16.h"
@@ -33,11 +35,16 @@ typedef _Float16 rf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int RD = 256;                    // model width (the only one built: encoder_dim = decoder_dim = 256 in every BASELINE config)
 constexpr int RBM = 32;                    // token rows per workgroup
-constexpr int RNW = 4, RNT = 256;          // waves / threads per workgroup
+#ifndef BDETR_RC_WAVES
+#define BDETR_RC_WAVES 8
+#endif
+constexpr int RNW = BDETR_RC_WAVES, RNT = 64 * RNW;      // waves / threads per workgroup (4 or 8)
+constexpr int TPW = 8 / RNW;               // 32-feature tiles per wave
+static_assert(RNW == 4 || RNW == 8, "the eight feature tiles split over 4 or 8 waves");
 constexpr int ROWB = 2 * RD + 16;          // bytes per token row of one LDS plane: +16 makes the 16-byte fragment reads of 16 lanes hit 64 distinct banks
 constexpr int PLANE = RBM * ROWB;          // hi plane, then lo plane
 #ifndef BDETR_RC_PF
-#define BDETR_RC_PF 4
+#define BDETR_RC_PF 8
 #endif
 constexpr int PF = BDETR_RC_PF;           // k-steps of weight fragments in flight
 constexpr int KSTEPS = RD / 16;
@@ -61,11 +68,11 @@ struct Lane {                              // who this lane is inside the workgr
     bool ok;                               // the lane's token exists
 };
 // registers: v[t][q] = features fbase + 32 t + 8 q + {0,1,2,3} of the lane's token (t = tile, q = accumulator quad: e = 4 q + c)
-typedef f32x4 Tile[2][4];
+typedef f32x4 Tile[TPW][4];
 
-__device__ __forceinline__ void tile_from_acc(const f32x16 (&acc)[2], Tile& v) {
+__device__ __forceinline__ void tile_from_acc(const f32x16 (&acc)[TPW], Tile& v) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < TPW; ++t)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -74,7 +81,7 @@ __device__ __forceinline__ void tile_from_acc(const f32x16 (&acc)[2], Tile& v) {
 __device__ __forceinline__ void tile_load(const float* __restrict__ base, const Lane& L, Tile& v) {
     const float* row = base + (int64_t)(L.m0 + L.j) * RD + L.fbase;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < TPW; ++t)
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[t][q] = L.ok ? *reinterpret_cast<const f32x4*>(row + 32 * t + 8 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
 }
@@ -82,13 +89,13 @@ __device__ __forceinline__ void tile_store(float* __restrict__ base, const Lane&
     if (!L.ok) return;
     float* row = base + (int64_t)(L.m0 + L.j) * RD + L.fbase;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < TPW; ++t)
 #pragma unroll
         for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(row + 32 * t + 8 * q) = v[t][q];
 }
 __device__ __forceinline__ void vec_load(const float* __restrict__ vec, const Lane& L, Tile& v) {     // a per-feature parameter in the lane's layout
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < TPW; ++t)
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[t][q] = *reinterpret_cast<const f32x4*>(vec + L.fbase + 32 * t + 8 * q);
 }
@@ -96,7 +103,7 @@ __device__ __forceinline__ void vec_load(const float* __restrict__ vec, const La
 template <bool F16>
 __device__ __forceinline__ void tile_to_lds(unsigned char* lds, const Lane& L, const Tile& v) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < TPW; ++t)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             u32x2 hi, lo;
@@ -125,21 +132,21 @@ __device__ __forceinline__ f32x16 mfma3(const u32x4& ah, const u32x4& al, const 
 }
 
 // The weight fragments of k-step s (global step = 16 * stage + s) for the wave's two feature tiles: [tile][plane].
-struct WFrag { u32x4 a[2][2]; };
+struct WFrag { u32x4 a[TPW][2]; };
 __device__ __forceinline__ void wfrag_load(WFrag& f, const u32x4* __restrict__ wp, int wave, int lane, int s) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < TPW; ++t)
 #pragma unroll
-        for (int p = 0; p < 2; ++p) f.a[t][p] = wp[(((2 * wave + t) * KSTEPS + s) * 2 + p) * 64 + lane];
+        for (int p = 0; p < 2; ++p) f.a[t][p] = wp[(((TPW * wave + t) * KSTEPS + s) * 2 + p) * 64 + lane];
 }
 
 // One GEMM stage: acc[t] = W[features of tile t][:] . X[token][:] over the 256-deep reduction, X from the LDS planes.  `ring`
 // holds the fragments of this stage's first PF k-steps on entry and of `wnext`'s first PF k-steps on exit.
 template <bool F16>
 __device__ __forceinline__ void gemm_stage(const u32x4* __restrict__ wp, const u32x4* __restrict__ wnext, const unsigned char* lds,
-                                           const Lane& L, int lane, WFrag (&ring)[PF], f32x16 (&acc)[2]) {
+                                           const Lane& L, int lane, WFrag (&ring)[PF], f32x16 (&acc)[TPW]) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < TPW; ++t)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
     const unsigned char* brow = lds + L.j * ROWB + L.lh * 16;
@@ -148,7 +155,7 @@ __device__ __forceinline__ void gemm_stage(const u32x4* __restrict__ wp, const u
         const u32x4 bh = *reinterpret_cast<const u32x4*>(brow + 32 * s);
         const u32x4 bl = *reinterpret_cast<const u32x4*>(brow + PLANE + 32 * s);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) acc[t] = mfma3<F16>(ring[s % PF].a[t][0], ring[s % PF].a[t][1], bh, bl, acc[t]);
+        for (int t = 0; t < TPW; ++t) acc[t] = mfma3<F16>(ring[s % PF].a[t][0], ring[s % PF].a[t][1], bh, bl, acc[t]);
         // The slot's MFMAs have issued: refill it for k-step s + PF.  The scheduling barriers keep the loads HERE - without them the
         // machine scheduler sinks every load to just in front of its first use (vmcnt(1) before each MFMA: no prefetch at all, measured
         // 11 us per stage instead of ~3).
@@ -159,20 +166,22 @@ __device__ __forceinline__ void gemm_stage(const u32x4* __restrict__ wp, const u
     }
 }
 
-// sums over the 256 features of every token: a lane's 32 values, its half-wave partner, then the four waves through LDS.
+// sums over the 256 features of every token: a lane's 16 * TPW values, its half-wave partner, then the RNW waves through LDS.
 // `red` region: [2][RNW][RBM] floats, one region per call site so that a single barrier per reduction is enough.
 __device__ __forceinline__ void row_reduce2(float& a, float& b, float* red, const Lane& L) {
     a += __shfl_xor(a, 32, 64);
     b += __shfl_xor(b, 32, 64);
     if (L.lh == 0) { red[L.wave * RBM + L.j] = a; red[RNW * RBM + L.wave * RBM + L.j] = b; }
     __syncthreads();
-    a = red[L.j] + red[RBM + L.j] + red[2 * RBM + L.j] + red[3 * RBM + L.j];
-    b = red[RNW * RBM + L.j] + red[RNW * RBM + RBM + L.j] + red[RNW * RBM + 2 * RBM + L.j] + red[RNW * RBM + 3 * RBM + L.j];
+    float sa = red[L.j], sb = red[RNW * RBM + L.j];
+#pragma unroll
+    for (int w = 1; w < RNW; ++w) { sa += red[w * RBM + L.j]; sb += red[RNW * RBM + w * RBM + L.j]; }      // (4 waves: the same left-to-right order as before)
+    a = sa; b = sb;
 }
 __device__ __forceinline__ float tile_sum(const Tile& v) {
     float s = 0.f;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < TPW; ++t)
 #pragma unroll
         for (int q = 0; q < 4; ++q) s += (v[t][q][0] + v[t][q][1]) + (v[t][q][2] + v[t][q][3]);
     return s;
@@ -185,7 +194,7 @@ __device__ __forceinline__ void add_drop_ln(Tile& y, const Tile& r, Tile& s_out,
     const float inv_keep = rate > 0.f ? 1.0f / (1.0f - rate) : 1.0f;
     const uint64_t row0 = (uint64_t)(L.m0 + L.j) * RD + L.fbase;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < TPW; ++t)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -199,7 +208,7 @@ __device__ __forceinline__ void add_drop_ln(Tile& y, const Tile& r, Tile& s_out,
     mean = s * (1.0f / RD);
     float qv = 0.f;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < TPW; ++t)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -208,7 +217,7 @@ __device__ __forceinline__ void add_drop_ln(Tile& y, const Tile& r, Tile& s_out,
     row_reduce2(qv, dummy, red + 2 * RNW * RBM, L);
     rstd = 1.0f / sqrtf(qv * (1.0f / RD) + eps);
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < TPW; ++t)
 #pragma unroll
         for (int q = 0; q < 4; ++q) y[t][q] = (s_out[t][q] - mean) * rstd * g[t][q] + b[t][q];
 }
@@ -232,7 +241,7 @@ __global__ __launch_bounds__(RNT) void rowchain_fwd_kernel(bdetr_rowchain_fwd_ar
     const int tid = threadIdx.x, lane = tid & 63;
     Lane L;
     L.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    L.j = lane & 31; L.lh = lane >> 5; L.fbase = 64 * L.wave + 4 * L.lh;
+    L.j = lane & 31; L.lh = lane >> 5; L.fbase = 32 * TPW * L.wave + 4 * L.lh;
     L.m0 = blockIdx.x * RBM; L.M = a.M; L.ok = L.m0 + L.j < a.M;
     uint64_t seed1 = a.seed1, seed2 = a.seed2;
     if (a.seed_base != nullptr) { const uint64_t sb = *a.seed_base * 0x100000001B3ull; seed1 ^= sb; seed2 ^= sb; }
@@ -262,7 +271,7 @@ __global__ __launch_bounds__(RNT) void rowchain_fwd_kernel(bdetr_rowchain_fwd_ar
     }
     __syncthreads();
 
-    f32x16 acc[2];
+    f32x16 acc[TPW];
     Tile y, r, s;
     float mean, rstd;
     constexpr float WS = 1.0f / P16_W_SCALE;
@@ -276,7 +285,7 @@ __global__ __launch_bounds__(RNT) void rowchain_fwd_kernel(bdetr_rowchain_fwd_ar
     gemm_stage<true>(w0, w1, lds, L, lane, ring, acc);
     tile_from_acc(acc, y);
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < TPW; ++t)
 #pragma unroll
         for (int q = 0; q < 4; ++q) y[t][q] = y[t][q] * WS + bia[t][q];
     add_drop_ln(y, r, s, gam, bet, a.eps, a.rate, seed1, red[0], L, mean, rstd);
@@ -294,7 +303,7 @@ __global__ __launch_bounds__(RNT) void rowchain_fwd_kernel(bdetr_rowchain_fwd_ar
     Tile hh;
     tile_from_acc(acc, hh);
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < TPW; ++t)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -310,7 +319,7 @@ __global__ __launch_bounds__(RNT) void rowchain_fwd_kernel(bdetr_rowchain_fwd_ar
     Tile f;
     tile_from_acc(acc, f);
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < TPW; ++t)
 #pragma unroll
         for (int q = 0; q < 4; ++q) f[t][q] = f[t][q] * WS + bia[t][q];
     add_drop_ln(f, y, s, gam, bet, a.eps, a.rate, seed2, red[2], L, mean, rstd);
@@ -337,8 +346,8 @@ struct bdetr_rowchain_bwd_args {
 namespace {
 
 // one butterfly step: exchange with lane ^ N; the N values whose index bit matches the lane's token bit survive (compile-time indices only)
-template <int N>
-__device__ __forceinline__ void col_butterfly(float (&x)[32], int j) {
+template <int N, int LEN>
+__device__ __forceinline__ void col_butterfly(float (&x)[LEN], int j) {
     const bool up = (j & N) != 0;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
@@ -352,20 +361,26 @@ __device__ __forceinline__ void col_butterfly(float (&x)[32], int j) {
 // own token bit - so 31 exchanges instead of 160.  Lane (j, lh) ends up with the total of value number j of its half:
 // value n <-> (t = n >> 4, e = n & 15) <-> feature fbase + 32 t + 8 (e >> 2) + (e & 3).  Invalid tokens must hold zeros.
 __device__ __forceinline__ void col_reduce_store(const Tile& v, float* __restrict__ dst /* [256] */, const Lane& L) {
-    float x[32];
+    float x[16 * TPW];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < TPW; ++t)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int c = 0; c < 4; ++c) x[16 * t + 4 * q + c] = v[t][q][c];
-    col_butterfly<16>(x, L.j);
+    if constexpr (TPW == 2) {
+        col_butterfly<16>(x, L.j);
+    } else {
+        // one tile per wave (eight waves): 16 values for 32 tokens - token bit 4 folds without halving, lanes j and j ^ 16 end up equal
+#pragma unroll
+        for (int i = 0; i < 16; ++i) x[i] += __shfl_xor(x[i], 16, 64);
+    }
     col_butterfly<8>(x, L.j);
     col_butterfly<4>(x, L.j);
     col_butterfly<2>(x, L.j);
     col_butterfly<1>(x, L.j);
-    const int n = L.j, t = n >> 4, e = n & 15;
-    dst[L.fbase + 32 * t + 8 * (e >> 2) + (e & 3)] = x[0];
+    const int n = L.j, t = TPW == 2 ? n >> 4 : 0, e = n & 15;
+    if (TPW == 2 || n < 16) dst[L.fbase + 32 * t + 8 * (e >> 2) + (e & 3)] = x[0];
 }
 
 // LayerNorm backward of one row set: g = dout * gamma, xhat = (s - mean) * rstd, dh = (g - mean_f(g) - xhat * mean_f(g xhat)) * rstd.
@@ -375,7 +390,7 @@ __device__ __forceinline__ void ln_bwd(Tile& d, const Tile& s, Tile& g, float me
     Tile xh, dg;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < TPW; ++t)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             xh[t][q] = (s[t][q] - mean) * rstd;
@@ -389,7 +404,7 @@ __device__ __forceinline__ void ln_bwd(Tile& d, const Tile& s, Tile& g, float me
     row_reduce2(s1, s2, red, L);
     const float m1 = s1 * (1.0f / RD), m2 = s2 * (1.0f / RD);
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < TPW; ++t)
 #pragma unroll
         for (int q = 0; q < 4; ++q) d[t][q] = (g[t][q] - m1 - xh[t][q] * m2) * rstd;
 }
@@ -399,7 +414,7 @@ __device__ __forceinline__ void apply_keep(Tile& v, float rate, uint64_t seed, c
     const float inv_keep = 1.0f / (1.0f - rate);
     const uint64_t row0 = (uint64_t)(L.m0 + L.j) * RD + L.fbase;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < TPW; ++t)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -412,7 +427,7 @@ __global__ __launch_bounds__(RNT) void rowchain_bwd_kernel(bdetr_rowchain_bwd_ar
     const int tid = threadIdx.x, lane = tid & 63;
     Lane L;
     L.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    L.j = lane & 31; L.lh = lane >> 5; L.fbase = 64 * L.wave + 4 * L.lh;
+    L.j = lane & 31; L.lh = lane >> 5; L.fbase = 32 * TPW * L.wave + 4 * L.lh;
     L.m0 = blockIdx.x * RBM; L.M = a.M; L.ok = L.m0 + L.j < a.M;
     uint64_t seed1 = a.seed1, seed2 = a.seed2;
     if (a.seed_base != nullptr) { const uint64_t sb = *a.seed_base * 0x100000001B3ull; seed1 ^= sb; seed2 ^= sb; }
@@ -427,7 +442,7 @@ __global__ __launch_bounds__(RNT) void rowchain_bwd_kernel(bdetr_rowchain_bwd_ar
 #pragma unroll
         for (int s = 0; s < PF; ++s) wfrag_load(ring[s], first, L.wave, lane, s);
     }
-    f32x16 acc[2];
+    f32x16 acc[TPW];
     Tile d;                                  // the running gradient, in the lane's [feature][token] layout
     tile_load(a.dout, L, d);                 // (zeros for tokens beyond M: every partial sum below relies on that)
     // saved tensors of the FIRST LayerNorm and the hidden activations: requested now, consumed after one or two K loops
@@ -446,7 +461,7 @@ __global__ __launch_bounds__(RNT) void rowchain_bwd_kernel(bdetr_rowchain_bwd_ar
         ln_bwd(d, s2t, g2t, mean2, rstd2, red[0], part + 0 * RD, part + 1 * RD, L);
         Tile dres;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < TPW; ++t)
 #pragma unroll
             for (int q = 0; q < 4; ++q) dres[t][q] = d[t][q];
         apply_keep(d, a.rate, seed2, L);
@@ -458,7 +473,7 @@ __global__ __launch_bounds__(RNT) void rowchain_bwd_kernel(bdetr_rowchain_bwd_ar
         gemm_stage<false>(w2, w1, lds, L, lane, ring, acc);
         tile_from_acc(acc, d);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < TPW; ++t)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -472,7 +487,7 @@ __global__ __launch_bounds__(RNT) void rowchain_bwd_kernel(bdetr_rowchain_bwd_ar
         gemm_stage<false>(w1, wo, lds, L, lane, ring, acc);
         tile_from_acc(acc, d);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < TPW; ++t)
 #pragma unroll
             for (int q = 0; q < 4; ++q) d[t][q] += dres[t][q];
         __syncthreads();                     // (K loop done before the planes are rewritten below)
