@@ -43,7 +43,8 @@ constexpr int CH = 64;            // streamed rows per chunk
 constexpr int COLS_PER_BLOCK = 128;
 // Chunks of look-ahead of the streamed operand pair (a ring of register sets).  Measured round 4 (-DBDETR_ATTN_PF=3 against 1, whole step,
 // three alternating runs each on one box): 604.1 against 604.9 images/s - with three workgroups resident per CU the other workgroups
-// cover a chunk's HBM round trip already; 1 keeps the registers.
+// cover a chunk's HBM round trip already; 1 keeps the registers.  Measured again after the softmax change (40 -> 20 VALU instructions per MFMA): depth 2
+// equal (620 against 621 images/s), depth 3 slower (617; its backward launches 93 against 75 us: the extra register sets cost a resident workgroup).
 #ifndef BDETR_ATTN_PF
 #define BDETR_ATTN_PF 1
 #endif
