@@ -122,6 +122,7 @@ SIGNATURES = {
     "bdetr_colsum_chunks": (I, [L]),
     "bdetr_colsum": (I, [P, L, I, P, P, P]),
     "bdetr_colsum_accumulate": (I, [P, L, I, P, P]),
+    "bdetr_colsum_accumulate_group": (I, [P, P, I, P, I, P]),
     "bdetr_colstats": (I, [P, L, I, P, P, P]),
     "bdetr_bn_stats": (I, [P, L, I, P, P, I, F, F, I, P, P, P, P, P, P, P]),
     "bdetr_flag_nonfinite": (I, [P, L, P, P]),

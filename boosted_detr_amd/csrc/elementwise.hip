@@ -151,6 +151,26 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
         else part[(int64_t)blockIdx.y * cols + c] = v;
     }
 }
+// up to four independent column sums of the same width in one launch (blockIdx.z = member): out[m][c] += sum over rows of x[m][.][c]
+struct ColsumGroup { const float* x[4]; float* out[4]; int64_t rows[4]; int64_t rpc[4]; };
+__global__ __launch_bounds__(256) void colsum_group_kernel(ColsumGroup g, int cols) {
+    __shared__ float s[256];
+    const int z = blockIdx.z;
+    // (selects with constant indices: a run-time index into the by-value argument would push it to scratch memory)
+    const float* x = z == 0 ? g.x[0] : z == 1 ? g.x[1] : z == 2 ? g.x[2] : g.x[3];
+    float* out = z == 0 ? g.out[0] : z == 1 ? g.out[1] : z == 2 ? g.out[2] : g.out[3];
+    const int64_t rows = z == 0 ? g.rows[0] : z == 1 ? g.rows[1] : z == 2 ? g.rows[2] : g.rows[3];
+    const int64_t rpc = z == 0 ? g.rpc[0] : z == 1 ? g.rpc[1] : z == 2 ? g.rpc[2] : g.rpc[3];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    const int64_t r0 = (int64_t)blockIdx.y * rpc, r1 = min(rows, r0 + rpc);
+    if (r0 >= rows) return;                                    // (uniform: a member with fewer row chunks than the grid)
+    float a = 0.f;
+    if (c < cols) for (int64_t r = r0 + ry; r < r1; r += 4) a += x[r * cols + c];
+    s[threadIdx.x] = a;
+    __syncthreads();
+    if (ry == 0 && c < cols) atomicAdd(out + c, s[cx] + s[cx + 64] + s[cx + 128] + s[cx + 192]);
+}
 // 32 columns x 8 part-phases per block, fp64, fixed order
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int nparts, int cols, float* __restrict__ out) {
     __shared__ double s[256];
@@ -359,6 +379,23 @@ extern "C" int bdetr_colsum_accumulate(const float* x, int64_t rows, int cols, f
     int nch = (int)cdiv64(rows, rpc);
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 63) / 64, nch), dim3(256), 0, (hipStream_t)stream, x, rows, cols, rpc, (float*)nullptr, out);
     return bdetr_launch_status("colsum_accumulate");
+}
+
+// n <= 4 column sums of one width in ONE launch (the bias gradients of an attention block's Q / K / V projections, transformers.py:68-70
+// + autodiff): outs[m][c] += sum over rows[m] of xs[m][.][c], float atomics like bdetr_colsum_accumulate (outs must hold zeros or the
+// running sum).  xs / rows / outs are HOST arrays of n entries.
+extern "C" int bdetr_colsum_accumulate_group(const float* const* xs, const int64_t* rows, int cols, float* const* outs, int n, void* stream) {
+    BDETR_CHECK_ARG(xs && rows && outs && cols > 0 && n >= 1 && n <= 4, "bdetr_colsum_accumulate_group: bad arguments (1 <= n <= 4)");
+    ColsumGroup g{};
+    int nch = 1;
+    for (int m = 0; m < n; ++m) {
+        BDETR_CHECK_ARG(xs[m] && outs[m] && rows[m] > 0, "bdetr_colsum_accumulate_group: null / empty member %d", m);
+        g.x[m] = xs[m]; g.out[m] = outs[m]; g.rows[m] = rows[m]; g.rpc[m] = colsum_rows_per_chunk(rows[m], cols);
+        nch = max(nch, (int)cdiv64(rows[m], g.rpc[m]));
+    }
+    for (int m = n; m < 4; ++m) { g.x[m] = xs[0]; g.out[m] = outs[0]; g.rows[m] = 0; g.rpc[m] = 1; }
+    hipLaunchKernelGGL(colsum_group_kernel, dim3((cols + 63) / 64, nch, n), dim3(256), 0, (hipStream_t)stream, g, cols);
+    return bdetr_launch_status("colsum_accumulate_group");
 }
 
 extern "C" int bdetr_colsum_chunks(int64_t rows) { return (int)cdiv64(rows, 32); }   // upper bound for any cols

@@ -625,6 +625,17 @@ def colsum(x2d, out=None, prezeroed=False):
     return out
 
 
+def colsum_group(xs, outs):
+    """out[m] += column sums of xs[m] for up to four [rows_m, cols] tensors of one width in ONE launch (float atomics: every out[m] must
+    hold zeros or the running sum; the callers fall back to `colsum` per tensor in deterministic mode)."""
+    _chk(*xs, *outs)
+    n, cols = len(xs), xs[0].shape[1]
+    assert 1 <= n <= 4 and all(x.dim() == 2 and x.shape[1] == cols for x in xs) and all(o.numel() == cols for o in outs)
+    PA, LA = C.c_void_p * n, C.c_int64 * n
+    check(_lib.lib().bdetr_colsum_accumulate_group(PA(*[x.data_ptr() for x in xs]), LA(*[x.shape[0] for x in xs]), cols, PA(*[o.data_ptr() for o in outs]), n,
+                                                   _stream()), "colsum_accumulate_group")
+
+
 # --------------------------------------------------------------------------------------
 # BatchNorm
 # --------------------------------------------------------------------------------------

@@ -591,11 +591,17 @@ def dense_group(xs, ws, bs):
                 K.linear_bwd_weight_group([m[0] for m in members], [m[1] for m in members], [m[2].buf for m in members], [m[2].mode == "direct" for m in members])
                 for m in members:
                     m[2].commit()
-            for g, b in zip(g2, bs):
-                if b.needs_grad:
-                    s = GradSink(b)
-                    K.colsum(g, out=s.buf, prezeroed=s.mode == "direct")
+            # bias gradients: the members whose sink is a zero-filled slice of the flat gradient buffer share ONE launch
+            sinks = [(g, GradSink(b)) for g, b in zip(g2, bs) if b.needs_grad]
+            direct = [(g, s) for g, s in sinks if s.mode == "direct"]
+            if len(direct) > 1 and not K.deterministic() and all(g.shape[1] == direct[0][0].shape[1] for g, _ in direct):
+                K.colsum_group([g for g, _ in direct], [s.buf for _, s in direct])
+                for _, s in direct:
                     s.commit()
+                sinks = [(g, s) for g, s in sinks if s.mode != "direct"]
+            for g, s in sinks:
+                K.colsum(g, out=s.buf, prezeroed=s.mode == "direct")
+                s.commit()
         if any(w.needs_grad or b.needs_grad for w, b in zip(ws, bs)):
             side_task(param_grads, *x2, *g2)
         dxs = K.linear_bwd_data_group(g2, [w.value for w in ws])

@@ -298,6 +298,9 @@ int bdetr_colsum(const float* x, int64_t rows, int cols, float* out, float* ws, 
 /* the same sum ADDED into out with float atomics in one launch (no workspace): out must hold zeros or the running
  * sum - the host's flat gradient buffer is zero-filled once per step */
 int bdetr_colsum_accumulate(const float* x, int64_t rows, int cols, float* out, void* stream);
+/* n <= 4 such column sums of one width in ONE launch (the bias gradients of an attention block's Q / K / V projections,
+ * transformers.py:68-70 + autodiff).  xs / rows / outs are HOST arrays of n entries; outs[m] must hold zeros or the running sum. */
+int bdetr_colsum_accumulate_group(const float* const* xs, const int64_t* rows, int cols, float* const* outs, int n, void* stream);
 
 /* ------------------------------------------------------------------------
  * K3  BatchNormalization, training mode (keras BN inside ResNet-50, backbone.py:79-80,

@@ -67,6 +67,19 @@ def test_linear_bwd(cuda, M, K, O):
     assert torch.equal(d1, d2) and torch.equal(a1, a2)
 
 
+def test_colsum_group(cuda):
+    """bdetr_colsum_accumulate_group: up to four column sums of one width in one launch (the Q / K / V bias gradients), ragged row counts,
+    onto a running sum - against fp64."""
+    from boosted_detr_amd import kernels as k
+    for rows in ([6400, 6400, 6400], [1600, 6400, 6400, 33], [7, 1]):
+        xs = [rnd(r, 256, seed=10 + i) for i, r in enumerate(rows)]
+        base = [rnd(256, seed=50 + i) for i in range(len(rows))]
+        outs = [dev(b) for b in base]
+        k.colsum_group([dev(x) for x in xs], outs)
+        for x, b, o in zip(xs, base, outs):
+            close(o, b.double() + x.double().sum(0), rtol=1e-5)
+
+
 def test_gemm_batched_attention_shapes(cuda):
     """QK^T, PV and dV with the [B,q,h,d] strides the attention block uses, incl. unaligned T=49."""
     from boosted_detr_amd import kernels as k
