@@ -354,9 +354,13 @@ def main():
         model.distribute()
     want_graph = not args.no_graph and os.environ.get("BDETR_GRAPH", "1") != "0"
     # N > 1 replays too: the bucket all-reduces are captured into the chain (Model._graph_step; rehearsed over a one-rank RCCL
-    # communicator - tests/test_dp_gpu.py - no multi-GPU node was available to this build).  BDETR_DP_GRAPH=0 keeps the eagerly enqueued
-    # data-parallel step (collectives issued per bucket from the backward pass on a communication stream), and a capture that raises
-    # falls back to it on every rank (the ranks agree through a MIN all-reduce).
+    # communicator - tests/test_dp_gpu.py - no multi-GPU node was available to this build).  Every rank takes the same decision from the
+    # same flags and environment BEFORE any capture, no eager collective is issued between the eager set-up steps and the captured one
+    # (Model._graph_step drains the outstanding ones first), and a capture that fails under N > 1 is fatal: the other ranks are inside
+    # their own capture of the same collectives, there is nothing sound to fall back to mid-capture.  (Round 4's "MIN all-reduce, then
+    # eager on every rank" fallback could not catch what actually happened - a std::terminate on the RCCL watchdog thread, now fixed at
+    # its cause: engine.SegmentedCapture.CAPTURE_ERROR_MODE.)  BDETR_DP_GRAPH=0 keeps the eagerly enqueued data-parallel step
+    # (collectives issued per bucket from the backward pass on a communication stream).
     if distributed and os.environ.get("BDETR_DP_GRAPH", "1") == "0":
         want_graph = False
     model.use_graph = want_graph and graph_ok
@@ -378,23 +382,16 @@ def main():
     if model.use_graph:
         # build-by-first-call, allocator warm-up and the capture itself (third step on a signature) are set-up, like the build:
         # they happen before the W warm-up steps, so that warm-up and timed steps are all replays whatever W is
-        capture_failed = None
         for i in range(7 if distributed else 4):           # (data-parallel: two more eager steps first - replica broadcast, bucket-table calibration)
             tw = time.perf_counter()
             try:
                 run_step(batch)
-            except Exception as exc:                       # (a failed capture leaves the stream usable: SegmentedCapture.abort)
-                if not distributed:
-                    raise
-                capture_failed = repr(exc)[:300]
-            ok = torch.tensor([0 if capture_failed else 1], dtype=torch.int32, device="cuda")
-            if dist is not None:
-                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 0:
-                note(f"graph capture of the data-parallel step failed on some rank ({capture_failed}): eagerly enqueued steps instead")
-                model.use_graph, model._graphs, model._graph_warm = False, {}, {}
-                graph_fallback = capture_failed or "another rank"
-                break
+            except Exception as exc:
+                if distributed:
+                    print(f"[bench] rank {rank}: capture of the data-parallel step failed ({exc!r}); fatal under N > 1 "
+                          "(rerun with BDETR_DP_GRAPH=0 for the eagerly enqueued step)", file=sys.stderr, flush=True)
+                    os._exit(3)                             # (not sys.exit: the other ranks may be blocked in a captured collective's set-up)
+                raise
             torch.cuda.synchronize()
             note(f"set-up step {i} ({'captured' if model._graphs else 'eager'}): {(time.perf_counter() - tw) * 1e3:.1f} ms")
             if model._graphs:

@@ -128,6 +128,7 @@ SIGNATURES = {
     "bdetr_flag_nonfinite": (I, [P, L, P, P]),
     "bdetr_flag_snapshot": (I, [P, P, P, I, P]),
     "bdetr_debug_checksum": (I, [P, L, P, P, P, I, U64, P]),
+    "bdetr_graph_node_census": (I, [P, P, I]),
     "bdetr_bn_stats_fold_rows": (I, []),
     "bdetr_bn_stats_frozen": (I, [P, P, I, F, P, P, P]),
     "bdetr_bn_apply": (I, [P, P, P, P, P, P, I, P, L, I, P]),
@@ -205,7 +206,7 @@ def lib():
         fn = getattr(h, name)          # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if h.bdetr_abi_version() != 6:
+    if h.bdetr_abi_version() != 7:
         raise BdetrError("libbdetr.so ABI version mismatch; rebuild")
     _lib = h
     return _lib

@@ -34,3 +34,26 @@ extern "C" int bdetr_stream_priority_range(int* least, int* greatest) {
     if (e != hipSuccess) { bdetr_set_error("bdetr_stream_priority_range: %s", hipGetErrorString(e)); return (int)e; }
     return 0;
 }
+
+// Census of a captured hipGraph's nodes by hipGraphNodeType (counts[t] for t < ncounts; types beyond go to counts[ncounts - 1]).
+// The replay path's soundness rests on "kernel nodes only" (a hipMemset node replayed wrongly in round 4): engine.SegmentedCapture
+// checks it after capturing when BDETR_GRAPH_CENSUS=1, tests/test_training_gpu.py always.
+extern "C" int bdetr_graph_node_census(void* graph, int64_t* counts, int ncounts) {
+    BDETR_CHECK_ARG(graph != nullptr && counts != nullptr && ncounts > 0, "bdetr_graph_node_census: bad arguments");
+    for (int i = 0; i < ncounts; ++i) counts[i] = 0;
+    size_t n = 0;
+    hipError_t e = hipGraphGetNodes((hipGraph_t)graph, nullptr, &n);
+    if (e != hipSuccess) { bdetr_set_error("bdetr_graph_node_census: hipGraphGetNodes: %s", hipGetErrorString(e)); return (int)e; }
+    if (n == 0) return 0;
+    hipGraphNode_t* nodes = (hipGraphNode_t*)malloc(n * sizeof(hipGraphNode_t));
+    if (!nodes) { bdetr_set_error("bdetr_graph_node_census: out of host memory"); return (int)hipErrorOutOfMemory; }
+    e = hipGraphGetNodes((hipGraph_t)graph, nodes, &n);
+    for (size_t i = 0; e == hipSuccess && i < n; ++i) {
+        hipGraphNodeType t;
+        e = hipGraphNodeGetType(nodes[i], &t);
+        if (e == hipSuccess) counts[(int)t < ncounts ? (int)t : ncounts - 1] += 1;
+    }
+    free(nodes);
+    if (e != hipSuccess) { bdetr_set_error("bdetr_graph_node_census: %s", hipGetErrorString(e)); return (int)e; }
+    return 0;
+}

@@ -386,6 +386,14 @@ def _debug_cut(extra) -> None:
 
 class SegmentedCapture:
     SIDE_TASKS_PER_SEGMENT = int(_os.environ.get("BDETR_GRAPH_SEG", "10"))
+    # hipStreamCaptureModeThreadLocal, not torch's default "global".  Under the global mode HIP refuses capture-unsafe calls from EVERY
+    # thread of the process while a capture is open, and torch's ProcessGroupNCCL watchdog thread polls hipEventQuery on the end events of
+    # eager collectives that are still on its list (it retires them on its own ~100 ms tick): a query that lands inside a segment's
+    # capture returns hipErrorStreamCaptureUnsupported, the watchdog throws on its own thread and the process aborts (round 4:
+    # profiles/r04_sigabrt_capture_vs_rccl_watchdog.log).  All launches of a step come from the one thread that opened the capture, so the
+    # thread-local mode checks exactly what has to be checked; tests/test_dp_gpu.py holds the race open deterministically (a thread
+    # that queries an event throughout a capture).
+    CAPTURE_ERROR_MODE = _os.environ.get("BDETR_CAPTURE_MODE", "thread_local")
 
     def __init__(self):
         self.pool_main, self.pool_side = torch.cuda.graph_pool_handle(), torch.cuda.graph_pool_handle()
@@ -395,9 +403,35 @@ class SegmentedCapture:
         self._cur = None
         self.in_side = False
 
+    # BDETR_GRAPH_CENSUS=1 (and tests): keep every captured hipGraph_t and count its nodes by type after the capture; anything but
+    # kernel nodes (type 0) and empty / event-record / wait-event nodes of the capture's own joins (types 4, 7, 8) fails the capture.
+    # A memset or memcpy node is what made a replay diverge in round 4 (bdetr_graph_node_census, include/bdetr.h).
+    CENSUS = _os.environ.get("BDETR_GRAPH_CENSUS", "0") == "1"
+    ALLOWED_NODE_TYPES = (0, 4, 7, 8)
+
+    def _new_graph(self):
+        return torch.cuda.CUDAGraph(keep_graph=True) if self.CENSUS else torch.cuda.CUDAGraph()
+
+    def census(self) -> Dict[int, int]:
+        """Node counts by hipGraphNodeType over every captured segment (needs CENSUS at capture time); raises on a disallowed type."""
+        import ctypes
+        from . import _lib
+        total: Dict[int, int] = {}
+        for g in list(self.mains) + [x for x in self.sides if x is not None]:
+            counts = (ctypes.c_int64 * 16)()
+            _lib.check(_lib.lib().bdetr_graph_node_census(ctypes.c_void_p(g.raw_cuda_graph()), counts, 16), "graph_node_census")
+            for t, c in enumerate(counts):
+                if c:
+                    total[t] = total.get(t, 0) + int(c)
+        bad = {t: c for t, c in total.items() if t not in self.ALLOWED_NODE_TYPES}
+        if bad:
+            raise RuntimeError(f"captured step holds non-kernel graph nodes {bad} (hipGraphNodeType: count); 1 = memcpy, 2 = memset: "
+                               "these replay unsoundly on this runtime - find the torch op that lowered to them")
+        return total
+
     def begin_main(self) -> None:
-        g = torch.cuda.CUDAGraph()
-        ctx = torch.cuda.graph(g, pool=self.pool_main, stream=self.cap_main)
+        g = self._new_graph()
+        ctx = torch.cuda.graph(g, pool=self.pool_main, stream=self.cap_main, capture_error_mode=self.CAPTURE_ERROR_MODE)
         ctx.__enter__()
         self._cur = (g, ctx)
         K.set_launch_stream(self.cap_main.cuda_stream)
@@ -429,8 +463,8 @@ class SegmentedCapture:
         if not self.pending:
             self.sides.append(None)
             return
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, pool=self.pool_side, stream=self.cap_side):
+        g = self._new_graph()
+        with torch.cuda.graph(g, pool=self.pool_side, stream=self.cap_side, capture_error_mode=self.CAPTURE_ERROR_MODE):
             prev = K.set_launch_stream(self.cap_side.cuda_stream)
             self.in_side = True                   # (a data-parallel bucket completed by one of these tasks is captured here, inline)
             try:

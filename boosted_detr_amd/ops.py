@@ -501,7 +501,7 @@ def conv_bn_relu_maxpool(x: torch.Tensor, w: Variable, b: Variable, bn: BNState,
         parts = K.colstats(_2d(y))
     mean, rstd = K.bn_stats(g.M, Kout, parts, bn.eps, bn.momentum, True, bn.moving_mean.value, bn.moving_var.value, like=y)
     _, out, tap = K.stem_pool_fwd(y, mean, rstd, bn.gamma.value, bn.beta.value)
-    out._p16f, out._p16b, out._p16_only = out, None, True
+    out._p16f, out._p16b, out._p16_only = out.view(out.shape), None, True      # (a view, not `out` itself: no reference cycle through __dict__)
 
     def backward(g_out):
         sg, sb = GradSink(bn.gamma), GradSink(bn.beta)

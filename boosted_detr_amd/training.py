@@ -354,6 +354,17 @@ class DataParallel:
             self.prof_steps.append({"base": self._prof_base, "buckets": self._prof_events})
             self._prof_events = []
 
+    def drain(self) -> None:
+        """Retire every collective this process has enqueued eagerly: wait on the handles still held, then idle the device.  Called once
+        before a data-parallel step is captured (Model._graph_step): a capture must not begin with eager collectives in flight - their
+        completion events are polled by the backend's watchdog thread (see engine.SegmentedCapture.CAPTURE_ERROR_MODE) and their
+        kernels would run concurrently with the capture's allocator warm-up."""
+        for h in getattr(self, "_handles", []):
+            h.wait()
+        self._handles = []
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+
     def profile_summary(self) -> Optional[dict]:
         """Per-step all-reduce time on the communication stream (union of the buckets' [start, end] intervals: buckets queue
         behind each other) and bandwidths, over the steps recorded while `profile` was on.  Synchronises the device."""
@@ -687,6 +698,8 @@ class Model(Layer):
             # backward pass, the weight-gradient tasks of each in a side graph that replays on the low-priority stream while
             # the next main segment runs, the optimizer in the last main segment behind the join.
             from . import engine as _engine
+            if getattr(self, "_dp", None) is not None:
+                self._dp.drain()                             # no eager collective in flight when the first segment's capture opens
             cap = _engine.SegmentedCapture()
             _engine._CAPTURE[0] = cap
             prev_launch = K.set_launch_stream(None)
@@ -703,6 +716,8 @@ class Model(Layer):
                 _engine._CAPTURE[0] = None
                 K.set_launch_stream(prev_launch)
             cap.done = []                                    # the deferred closures kept the crossing tensors alive during the capture
+            if cap.CENSUS:
+                self._graph_census = cap.census()            # raises if a memset / memcpy node entered the captured step
             self.steps_done, self.optimizer.iterations = keep         # capturing is not a step
             entry = (cap, static, logs, (list(self._step_losses), list(self._loss_roots), dict(self._step_metrics)))
             self._graphs[sig] = entry

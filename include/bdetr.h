@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define BDETR_ABI_VERSION 6
+#define BDETR_ABI_VERSION 7
 
 int         bdetr_abi_version(void);
 const char* bdetr_last_error(void);
@@ -331,6 +331,10 @@ int bdetr_flag_snapshot(const int* flag, int* ordinal, int* host_ring, int ring_
  * {wrapping sum of x's bit patterns, count of non-finite elements, tag} to log[3 * (*cursor)++] (device memory, `cap` entries;
  * scratch: two zeroed device words).  Order-independent, stream-ordered, capturable: every replay of a segment appends an entry. */
 int bdetr_debug_checksum(const float* x, int64_t n, uint64_t* scratch, uint64_t* log, int* cursor, int cap, uint64_t tag, void* stream);
+/* Diagnostic of the hipGraph replay path (ABI 7; no reference counterpart): counts[t] = nodes of hipGraphNodeType t in `graph` (a
+ * hipGraph_t; types >= ncounts are counted in the last slot).  The captured training step must hold kernel nodes only - a hipMemset node
+ * replayed wrongly on this runtime (round 4) - and engine.SegmentedCapture enforces that with this call under BDETR_GRAPH_CENSUS=1. */
+int bdetr_graph_node_census(void* graph, int64_t* counts, int ncounts);
 /* fold_ws (optional): 2*C*bdetr_bn_stats_fold_rows() floats; lets bn_stats pre-reduce thousands of
  * epilogue partial rows with a wide grid before the fp64 finalise */
 int bdetr_bn_stats_fold_rows(void);

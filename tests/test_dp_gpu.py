@@ -279,6 +279,25 @@ cfg, host = small_batch()
 params = O.make_params(cfg, seed=1)
 batch = {"image": to_device(host["image"]), "category": to_device(host["category"], torch.int32), "attribute": to_device(host["attribute"], torch.int32),
          "bbox": to_device(host["bbox"]), "num_objects": to_device(host["num_objects"], torch.int32)}
+# The round-4 abort, held open deterministically: a second host thread queries a device event every few hundred microseconds for the
+# whole run (that is what ProcessGroupNCCL's watchdog does to the eager all-reduces still on its list, on a ~100 ms tick).  Under the
+# global capture mode such a query fails with hipErrorStreamCaptureUnsupported whenever it lands inside a capture (the control below);
+# the segments capture in thread-local mode, so it must never fail here.
+import threading, time
+poll_stop, poll_errs, poll_n = threading.Event(), [], [0]
+def _poll():
+    torch.cuda.set_device(0)
+    ev = torch.cuda.Event(); ev.record()
+    while not poll_stop.is_set():
+        try:
+            ev.query()
+            poll_n[0] += 1
+        except Exception as exc:
+            poll_errs.append(repr(exc)[:300])
+            return
+        time.sleep(2e-4)
+poller = threading.Thread(target=_poll, daemon=True)
+poller.start()
 runs = {}
 for graph in (False, True):
     m = small_model(dropout=0.1)
@@ -292,12 +311,14 @@ for graph in (False, True):
         m.train_step(batch)                               # ... and four more without a host read in between
     m.guard_flush(); torch.cuda.synchronize()
     runs[graph] = (losses, m.get_weights_dict(), len(m._graphs), getattr(m._dp, "_captured_buckets", 0), len(m._dp._bounds))
+poll_stop.set(); poller.join()
+assert not poll_errs and poll_n[0] > 100, (poll_errs, poll_n)
 e, g = runs[False], runs[True]
 assert g[2] == 1 and g[3] >= g[4] >= 3 and e[2] == 0 and e[3] == 0, (g[2:], e[2:])      # every bucket's all-reduce is a node of the captured chain
 assert e[0] == g[0], (e[0], g[0])
 bad = [k for k in e[1] if not np.array_equal(e[1][k], g[1][k])]
 assert not bad, bad[:5]
-print("RCCL_GRAPH_DP_OK buckets", g[4], "captured all-reduces", g[3], "losses", g[0][:3])
+print("RCCL_GRAPH_DP_OK buckets", g[4], "captured all-reduces", g[3], "event queries from a second thread", poll_n[0], "losses", g[0][:3])
 dist.destroy_process_group()
 '''
 
@@ -315,3 +336,22 @@ def test_data_parallel_step_replays_as_hipgraphs_over_a_one_rank_rccl_communicat
     p = subprocess.run([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert p.returncode == 0 and "RCCL_GRAPH_DP_OK" in p.stdout, p.stdout[-3000:]
     print(p.stdout.strip().splitlines()[-1])
+
+
+def test_eager_collectives_on_the_watchdog_list_do_not_abort_a_capture(cuda):
+    """What killed round 4's driver run (profiles/r04_sigabrt_capture_vs_rccl_watchdog.log), made deterministic: 64 eager async all-reduces
+    are still on ProcessGroupNCCL's watchdog list when a capture opens and stays open for 1.5 s (tools/probes/rccl_capture_watchdog_probe.py).
+    Under the capture mode engine.SegmentedCapture uses, the process must survive; the control - torch's default global mode, what round 4
+    captured in - must abort on the watchdog thread, or the diagnosis (and this test) is wrong (profiles/r05_rccl_watchdog_vs_capture_mode.txt)."""
+    from boosted_detr_amd import engine
+    probe = os.path.join(ROOT, "tools", "probes", "rccl_capture_watchdog_probe.py")
+    out = {}
+    for mode in (engine.SegmentedCapture.CAPTURE_ERROR_MODE, "global"):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port(), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        p = subprocess.run([sys.executable, probe, "eager_then_capture", mode], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+        out[mode] = (p.returncode, "PROBE_OK" in p.stdout, "operation not permitted when stream is capturing" in p.stdout)
+    print(out)
+    assert engine.SegmentedCapture.CAPTURE_ERROR_MODE != "global"
+    assert out[engine.SegmentedCapture.CAPTURE_ERROR_MODE] == (0, True, False), out
+    rc, ok, refused = out["global"]
+    assert rc != 0 and not ok and refused, out
