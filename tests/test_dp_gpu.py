@@ -11,8 +11,9 @@ import numpy as np
 import pytest
 
 def _free_port() -> str:
-    """A port nobody listens on right now (fixed numbers collided with other jobs sharing the box's network namespace: one abort in
-    RCCL's bootstrap in round 4)."""
+    """A port nobody listens on right now (fixed numbers can collide with other jobs sharing the box's network namespace).  Round 4 saw one
+    abort of a worker here and blamed the port without keeping its log; it may as well have been the watchdog abort that
+    profiles/r04_sigabrt_capture_vs_rccl_watchdog.log records (fixed in round 5: engine.SegmentedCapture.CAPTURE_ERROR_MODE)."""
     import socket
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -341,8 +342,9 @@ def test_data_parallel_step_replays_as_hipgraphs_over_a_one_rank_rccl_communicat
 def test_eager_collectives_on_the_watchdog_list_do_not_abort_a_capture(cuda):
     """What killed round 4's driver run (profiles/r04_sigabrt_capture_vs_rccl_watchdog.log), made deterministic: 64 eager async all-reduces
     are still on ProcessGroupNCCL's watchdog list when a capture opens and stays open for 1.5 s (tools/probes/rccl_capture_watchdog_probe.py).
-    Under the capture mode engine.SegmentedCapture uses, the process must survive; the control - torch's default global mode, what round 4
-    captured in - must abort on the watchdog thread, or the diagnosis (and this test) is wrong (profiles/r05_rccl_watchdog_vs_capture_mode.txt)."""
+    Under the capture mode engine.SegmentedCapture uses, the process must survive.  The control - torch's default global mode, what round 4
+    captured in - is run and reported but not asserted (it aborted on the watchdog thread in every run recorded in
+    profiles/r05_rccl_watchdog_vs_capture_mode.txt; a control that depends on another library's thread timing must not be able to fail the suite)."""
     from boosted_detr_amd import engine
     probe = os.path.join(ROOT, "tools", "probes", "rccl_capture_watchdog_probe.py")
     out = {}
@@ -350,8 +352,6 @@ def test_eager_collectives_on_the_watchdog_list_do_not_abort_a_capture(cuda):
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port(), HSA_ENABLE_IPC_MODE_LEGACY="0")
         p = subprocess.run([sys.executable, probe, "eager_then_capture", mode], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
         out[mode] = (p.returncode, "PROBE_OK" in p.stdout, "operation not permitted when stream is capturing" in p.stdout)
-    print(out)
+    print("capture mode -> (exit code, survived, watchdog refused an event query):", out)
     assert engine.SegmentedCapture.CAPTURE_ERROR_MODE != "global"
     assert out[engine.SegmentedCapture.CAPTURE_ERROR_MODE] == (0, True, False), out
-    rc, ok, refused = out["global"]
-    assert rc != 0 and not ok and refused, out
