@@ -125,11 +125,13 @@ struct XXDense {
     using Row = int; using Step = int;                        // (RR-mode state: unused)
     static __device__ __forceinline__ unsigned records(const Op&) { return NUM_RECORDS; }
     struct Col { unsigned off; int r; bool ok; };             // running byte offset of (row r, the lane's chunk)
-    static __device__ __forceinline__ Col col(const Op& op, int x0, int slot, int x_lim, int r_first) {
+    // (r_uni: first row of the lane's wave-instruction - wave-uniform; lane_row: the lane's row inside it)
+    static __device__ __forceinline__ Col col(const Op& op, int x0, int slot, int x_lim, int r_uni, int lane_row) {
+        const int r_first = r_uni + lane_row;
         Col c; c.ok = x0 + 8 * (slot >> 1) < x_lim; c.r = r_first;
         c.off = (unsigned)r_first * op.ld * 4u + (unsigned)x0 * 4u + 16u * (unsigned)slot; return c;
     }
-    static __device__ __forceinline__ unsigned voff(const Op&, const Col& c, int r_lim) { return (c.ok && c.r < r_lim) ? c.off : OOB; }
+    template <int RPI> static __device__ __forceinline__ unsigned voff(const Op&, const Col& c, int r_lim) { return (c.ok && c.r < r_lim) ? c.off : OOB; }
     static __device__ __forceinline__ void advance(const Op& op, Col& c) { c.r += BK; c.off += (unsigned)BK * op.ld * 4u; }
 };
 struct XXPatch {
@@ -139,7 +141,8 @@ struct XXPatch {
     // (oh, ow) of the load's output pixel, (ih, iw) of the input pixel its tap reads, and the running byte offset of
     // that input pixel's channel chunk
     struct Col { int r, oh, ow, ih, iw; unsigned off; bool ok; };
-    static __device__ __forceinline__ Col col(const Op& op, int x0, int slot, int x_lim, int r_first) {
+    static __device__ __forceinline__ Col col(const Op& op, int x0, int slot, int x_lim, int r_uni, int lane_row) {
+        const int r_first = r_uni + lane_row;
         Col c; const int x = x0 + 8 * (slot >> 1);
         c.ok = x < x_lim; c.r = r_first;
         const int tap = x / op.C, ch = x - tap * op.C;
@@ -151,7 +154,7 @@ struct XXPatch {
         c.off = ((unsigned)(n * op.H * op.W) + (unsigned)(c.ih * op.W + c.iw)) * (unsigned)op.C * 4u + (unsigned)ch * 4u + 16u * (unsigned)(slot & 1);
         return c;
     }
-    static __device__ __forceinline__ unsigned voff(const Op& op, const Col& c, int r_lim) {
+    template <int RPI> static __device__ __forceinline__ unsigned voff(const Op& op, const Col& c, int r_lim) {
         const bool ok = c.ok && c.r < r_lim && (unsigned)c.ih < (unsigned)op.H && (unsigned)c.iw < (unsigned)op.W;
         return ok ? c.off : OOB;
     }
@@ -402,15 +405,15 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
         static_assert(SA >= 16 && SB >= 16 && SA <= 64 && SB <= 64, "XX tiles: 64 <= BX <= 256");
 #pragma unroll
         for (int t = 0; t < NIA; ++t) {
-            const int r = (t * NW + wave) * (64 / SA) + lane / SA;
+            const int ru = (t * NW + wave) * (64 / SA), r = ru + lane / SA;      // ru: wave-uniform first row of the wave-instruction
             rrA[t] = r;
-            colA[t] = LA::col(opa, i0, (lane % SA) ^ xx_swz(r), opa.cols, r_begin + r);
+            colA[t] = LA::col(opa, i0, (lane % SA) ^ xx_swz(r), opa.cols, r_begin + ru, lane / SA);
         }
 #pragma unroll
         for (int t = 0; t < NIB; ++t) {
-            const int r = (t * NW + wave) * (64 / SB) + lane / SB;
+            const int ru = (t * NW + wave) * (64 / SB), r = ru + lane / SB;
             rrB[t] = r;
-            colB[t] = LB::col(opb, j0, (lane % SB) ^ xx_swz(r), opb.cols, r_begin + r);
+            colB[t] = LB::col(opb, j0, (lane % SB) ^ xx_swz(r), opb.cols, r_begin + ru, lane / SB);
         }
     }
 
@@ -422,13 +425,13 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
             constexpr int t = l;
             unsigned vo;
             if constexpr (!XX) vo = LA::voff(opa, rowA[t], stA, r0, klimA);
-            else               vo = LA::voff(opa, colA[t], min(r_end, opa.rows));
+            else               vo = LA::template voff<256 / BM>(opa, colA[t], min(r_end, opa.rows));
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(sa + (t * NW + wave) * 1024), 16, (int)vo, 0, 0, 0);
         } else {
             constexpr int t = l - NIA;
             unsigned vo;
             if constexpr (!XX) vo = LB::voff(opb, rowB[t], stB, r0, klimB);
-            else               vo = LB::voff(opb, colB[t], min(r_end, opb.rows));
+            else               vo = LB::template voff<256 / BN>(opb, colB[t], min(r_end, opb.rows));
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void*)(sa + A_BYTES + (t * NW + wave) * 1024), 16, (int)vo, 0, 0, 0);
         }
     };
@@ -469,39 +472,65 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
         hi = *reinterpret_cast<const u32x4*>(p + s * 16);
         lo = *reinterpret_cast<const u32x4*>(p + (s ^ 1) * 16);
     };
-    auto frag_xx = [&](const unsigned char* tile, int rowbytes, int xw, int ks, u32x4& hi, u32x4& lo) {
+    // XX fragments: `ds_read_b64_tr_b16` as INLINE ASSEMBLY, with the s_waitcnt written by hand (frag_wait).  Round 5: through
+    // __builtin_amdgcn_ds_read_tr16_b64_v4i16 the compiler's wait-count pass treated every such read as possibly aliasing the LDS-DMA
+    // writes still in flight and put `s_waitcnt vmcnt(0)` in front of the first fragment read of a K-step - right behind the issue
+    // of the NEXT stage's loads.  The two-stage ring was thereby a one-stage ring in every weight-gradient kernel: each K-step
+    // waited out the round trip of the loads it had just issued (cycle stamps: 76 cycles waiting at the top of the step, 1,200-1,780
+    // in the "MFMA" section; profiles/r05_wgrad_kstep_stamps.txt).  The plain `ds_read_b128` of the RR kernels carry a memory operand the
+    // pass can reason about and never had the wait.  Ring safety is the barrier protocol's business, exactly as for the RR kernels:
+    // the stage being read landed before the barrier at the top of the K-step, the stage in flight is the other buffer.
+    auto frag_xx = [&](const unsigned char* tile, auto rowbytes_c, int xw, auto ks_c, u32x4& hi, u32x4& lo) {
         // ds_read_b64_tr_b16: lanes 16g .. 16g+15 read a 4-row x 16-column block, lane 4q+p supplies row q,
         // columns 4p .. 4p+3; lane i receives column i of the 4 rows.  Two reads (4 k each) per half.
+        constexpr int rowbytes = decltype(rowbytes_c)::value, ks = decltype(ks_c)::value;
         const int g16 = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3;
         const int unit = (xw + 16 * g16 + 4 * p) >> 3;                         // 8-column group
-        u32x2 h[2], l[2];
-#pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2) {
-            const int r = ks * 16 + 8 * lh + 4 * t2 + q;
-            const int s = (2 * unit) ^ xx_swz(r);
-            const unsigned char* ptr = tile + r * rowbytes + s * 16 + 8 * (p & 1);
-            h[t2] = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)ptr));
-            l[t2] = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + r * rowbytes + (s ^ 1) * 16 + 8 * (p & 1))));
+        const int r0 = 8 * lh + q;                                             // row of (ks = 0, t2 = 0); xx_swz reads bits 0-1 only: those of q
+        const int sl = (2 * unit) ^ xx_swz(r0);
+        const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char*)tile + (unsigned)(r0 * rowbytes + 8 * (p & 1));
+        const unsigned ah = base + (unsigned)(sl * 16), al = base + (unsigned)((sl ^ 1) * 16);
+        u32x2 h0, h1, l0, l1;
+        constexpr int o0 = ks * 16 * rowbytes, o1 = o0 + 4 * rowbytes;
+        static_assert(o1 < 65536, "ds offset field");
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(h0) : "v"(ah), "n"(o0));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(l0) : "v"(al), "n"(o0));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(h1) : "v"(ah), "n"(o1));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(l1) : "v"(al), "n"(o1));
+        hi[0] = h0[0]; hi[1] = h0[1]; hi[2] = h1[0]; hi[3] = h1[1];
+        lo[0] = l0[0]; lo[1] = l0[1]; lo[2] = l1[0]; lo[3] = l1[1];
+    };
+    // every fragment register of the K-step half passes through the wait: no use can be scheduled ahead of it
+    auto frag_wait = [&](u32x4 (&ah)[TM], u32x4 (&al)[TM], u32x4 (&bh)[TN], u32x4 (&bl)[TN]) {
+        if constexpr (XX) {
+            static_assert(TM <= 2 && TN <= 2, "frag_wait ties at most 2 + 2 fragments");
+            if constexpr (TM == 2 && TN == 2)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[0]), "+v"(al[0]), "+v"(ah[1]), "+v"(al[1]), "+v"(bh[0]), "+v"(bl[0]), "+v"(bh[1]), "+v"(bl[1]));
+            else if constexpr (TM == 2 && TN == 1)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[0]), "+v"(al[0]), "+v"(ah[1]), "+v"(al[1]), "+v"(bh[0]), "+v"(bl[0]));
+            else if constexpr (TM == 1 && TN == 2)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[0]), "+v"(al[0]), "+v"(bh[0]), "+v"(bl[0]), "+v"(bh[1]), "+v"(bl[1]));
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[0]), "+v"(al[0]), "+v"(bh[0]), "+v"(bl[0]));
         }
-        hi[0] = h[0][0]; hi[1] = h[0][1]; hi[2] = h[1][0]; hi[3] = h[1][1];
-        lo[0] = l[0][0]; lo[1] = l[0][1]; lo[2] = l[1][0]; lo[3] = l[1][1];
     };
     // One K-step: the MFMAs of stage `buf` with the NEXT stage's loads issued between the MFMA groups, in program
     // order (LDS-DMA writes and ds_reads may alias as far as the compiler knows, so it keeps this order): a load's
     // issue cost (address VALU + M0 + buffer_load ... lds) then hides in the shadow of the preceding MFMAs instead of
     // running as a serial preamble in front of them.
-    auto load_frags = [&](int buf, int ks, u32x4 (&ah)[TM], u32x4 (&al)[TM], u32x4 (&bh)[TN], u32x4 (&bl)[TN]) {
+    auto load_frags = [&](int buf, auto ks_c, u32x4 (&ah)[TM], u32x4 (&al)[TM], u32x4 (&bh)[TN], u32x4 (&bl)[TN]) {
+        constexpr int ks = decltype(ks_c)::value;
         const unsigned char* tA = lds + buf * STAGE_BYTES;
         const unsigned char* tB = tA + A_BYTES;
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
             if constexpr (!XX) frag_rr(tA, wm * WTM + a * 32 + li, ks, ah[a], al[a]);
-            else               frag_xx(tA, BM * 4, wm * WTM + a * 32, ks, ah[a], al[a]);
+            else               frag_xx(tA, std::integral_constant<int, BM * 4>{}, wm * WTM + a * 32, ks_c, ah[a], al[a]);
         }
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
             if constexpr (!XX) frag_rr(tB, wn * WTN + b * 32 + li, ks, bh[b], bl[b]);
-            else               frag_xx(tB, BN * 4, wn * WTN + b * 32, ks, bh[b], bl[b]);
+            else               frag_xx(tB, std::integral_constant<int, BN * 4>{}, wn * WTN + b * 32, ks_c, bh[b], bl[b]);
         }
     };
     auto mfma_ks = [&](const u32x4 (&ah)[TM], const u32x4 (&al)[TM], const u32x4 (&bh)[TN], const u32x4 (&bl)[TN]) {
@@ -540,10 +569,10 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
     // One K-step of the plain loops: fragment reads of one 16-deep half, its MFMAs, then the other half
     auto kstep = [&](int buf) {
         if (BDETR_DBG(g, 8)) return;                     // diagnostic builds: no fragment reads / MFMAs
-#pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
+        auto half = [&](auto ks_c) {
             u32x4 ah[TM], al[TM], bh[TN], bl[TN];
-            load_frags(buf, ks, ah, al, bh, bl);
+            load_frags(buf, ks_c, ah, al, bh, bl);
+            frag_wait(ah, al, bh, bl);
             if constexpr (XX && !F16) {
                 if (g.b_f16) {                           // weight gradients reading the forward's f16 pair of x (see GemmParams::b_f16)
 #pragma unroll
@@ -551,7 +580,10 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
                 }
             }
             mfma_ks(ah, al, bh, bl);
-        }
+        };
+        static_assert(BK / 16 == 2, "two 16-deep halves per stage");
+        half(std::integral_constant<int, 0>{});
+        half(std::integral_constant<int, 1>{});
     };
 
     // ---------------- main loop ----------------
@@ -576,8 +608,10 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
         u32x4 fah[2][TM], fal[2][TM], fbh[2][TN], fbl[2][TN];
         auto read_all = [&](auto buf_c) {
             constexpr int buf = decltype(buf_c)::value;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) load_frags(buf, ks, fah[ks], fal[ks], fbh[ks], fbl[ks]);
+            load_frags(buf, std::integral_constant<int, 0>{}, fah[0], fal[0], fbh[0], fbl[0]);
+            load_frags(buf, std::integral_constant<int, 1>{}, fah[1], fal[1], fbh[1], fbl[1]);
+            frag_wait(fah[0], fal[0], fbh[0], fbl[0]);
+            frag_wait(fah[1], fal[1], fbh[1], fbl[1]);
             if constexpr (XX && !F16) {
                 if (g.b_f16) {                           // (weight gradients reading the forward's f16 pair of x: converted here, in the shadow of the partner group's MFMAs)
 #pragma unroll
