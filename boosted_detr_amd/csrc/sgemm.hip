@@ -873,8 +873,8 @@ int launch_any(const typename LA::Op& a, const typename LB::Op& b, const GemmPar
         case T_128x64:     return launch_cfg<128, 64, 2, 2, 2, LA, LB, XX, F16>(a, b, g, zdim, st, kind);
         case T_PP256x128:
             // (the f16 flavour keeps two accumulator sets: with the fragments of a whole K-step resident it does not fit 256 VGPRs)
-            // (XX: the weight gradients on the ping-pong loop, round 4 - BDETR_WGRAD_PP, see wgrad_tile)
-            if constexpr ((std::is_same_v<LA, RRPatch> || XX) && !F16) return launch_cfg<256, 128, 4, 2, 3, LA, LB, XX, F16, true>(a, b, g, zdim, st, kind);
+            // (round 4 also ran the weight gradients on the ping-pong loop - BDETR_WGRAD_PP: slower on every layer, removed in round 5)
+            if constexpr (std::is_same_v<LA, RRPatch> && !F16) return launch_cfg<256, 128, 4, 2, 3, LA, LB, XX, F16, true>(a, b, g, zdim, st, kind);
             else return launch_cfg<128, 128, 2, 2, 2, LA, LB, XX, F16>(a, b, g, zdim, st, kind);
         case T_PP256x64:
             if constexpr (std::is_same_v<LA, RRPatch> && !F16) return launch_cfg<256, 64, 4, 2, 3, LA, LB, XX, F16, true>(a, b, g, zdim, st, kind);
@@ -1077,14 +1077,9 @@ extern "C" int bdetr_p16_conv2d_bwd_data_bnstats(const void* dy_bf16, const void
 
 static int wgrad_tile(const bdetr_conv_desc* d) {
     const int64_t Kd = (int64_t)d->R * d->S * d->C;
-    // BDETR_WGRAD_PP=1 (3x3 layers) / 2 (every layer): 256x128 tiles on the eight-wave ping-pong loop where the shape allows - a quarter
-    // less L2 -> LDS fill per FLOP than 128x128, the x conversion in the shadow of the partner group's MFMAs.  Measured (round 4,
-    // configs[1], 100 replayed steps, three alternating runs each): off 592.3 / 593.2 / 591.6 images/s, 3x3 layers 586.3 / 585.7 /
-    // 584.8, every layer 573.5 / 574.0 / 573.9.  One eight-wave workgroup per CU loses more to its serial prologue / atomic epilogue
-    // and to the halved slice count than the fill saves: OFF.
-    static int pp = -1;
-    if (pp < 0) { const char* e = getenv("BDETR_WGRAD_PP"); pp = e ? atoi(e) : 0; }
-    if (pp > 0 && d->K % 256 == 0 && Kd % 128 == 0 && (pp > 1 || !(d->R == 1 && d->S == 1))) return T_PP256x128;
+    // (Round 4 measured 256x128 ping-pong tiles here - BDETR_WGRAD_PP: 586 / 574 images/s for the 3x3 layers / every layer against 592;
+    // one eight-wave workgroup per CU loses more to its serial prologue / atomic epilogue and to the halved slice count than the fill
+    // saves.  Removed in round 5 together with its instantiations.)
     const int forced = forced_tile();
     if (forced >= 0 && d->K % TILE_BM[forced] == 0 && Kd % TILE_BN[forced] == 0) return forced;
     if (!(d->K % 128 == 0 && Kd % 128 == 0)) return T_64x64;
@@ -1119,8 +1114,12 @@ extern "C" int bdetr_p16_conv2d_bwd_weight_splitk(const bdetr_conv_desc* d) {
     }
     // floor, not ceil: all tiles x slices must fit the want_x * CUs resident slots at once - one workgroup more than
     // that runs alone in a second round and doubles the launch's duration
-    const int want = (d->R == 1 && d->S == 1) ? want_x : want_3x3;
-    int64_t sk = ((int64_t)(t == T_PP256x128 ? 1 : want) * num_cus()) / tiles;       // (the ping-pong tile: one workgroup of eight waves per CU)
+    // (3x3 layers on 64x64 tiles - the 64-channel layers of stage 2 - take three workgroups per CU: four fit, and the per-lane patch
+    // addressing of their loads wants more waves to hide behind; 0.156 -> 0.130 ms at 160x160x64, round 5, profiles/r05_wgrad_tile_sweep.txt)
+    static int want_64 = 0;
+    if (want_64 == 0) { const char* e64 = getenv("BDETR_WGRAD_WANT_64"); want_64 = e64 ? atoi(e64) : 3; if (want_64 < 1) want_64 = 1; }
+    const int want = (d->R == 1 && d->S == 1) ? want_x : (t == T_64x64 && getenv("BDETR_WGRAD_WANT_3X3") == nullptr ? want_64 : want_3x3);
+    int64_t sk = ((int64_t)want * num_cus()) / tiles;
     const int64_t maxsk = cdiv64(M, (int64_t)min_stages * BK);       // keep >= min_stages K-steps per split
     if (sk > maxsk) sk = maxsk;
     if (sk < 1) sk = 1;
