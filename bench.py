@@ -301,6 +301,7 @@ def main():
     # enable_graph_replay(): the explicit opt-in to DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 - nothing in this process has touched the GPU yet.
     # Since round 4 the replay does not depend on it (the memset nodes that misbehaved are gone: boosted_detr_amd/__init__.py); it stays
     # the bench's configuration because it is the one with the 2000-step soak behind it, and the line records whether it is in force.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (this pool's driver only supports dmabuf IPC: RCCL needs it in every rank's environment)
     import boosted_detr_amd
     graph_ok = boosted_detr_amd.enable_graph_replay()
     import torch
@@ -353,15 +354,17 @@ def main():
     if distributed:
         model.distribute()
     want_graph = not args.no_graph and os.environ.get("BDETR_GRAPH", "1") != "0"
-    # N > 1 replays too: the bucket all-reduces are captured into the chain (Model._graph_step; rehearsed over a one-rank RCCL
-    # communicator - tests/test_dp_gpu.py - no multi-GPU node was available to this build).  Every rank takes the same decision from the
-    # same flags and environment BEFORE any capture, no eager collective is issued between the eager set-up steps and the captured one
-    # (Model._graph_step drains the outstanding ones first), and a capture that fails under N > 1 is fatal: the other ranks are inside
-    # their own capture of the same collectives, there is nothing sound to fall back to mid-capture.  (Round 4's "MIN all-reduce, then
-    # eager on every rank" fallback could not catch what actually happened - a std::terminate on the RCCL watchdog thread, now fixed at
-    # its cause: engine.SegmentedCapture.CAPTURE_ERROR_MODE.)  BDETR_DP_GRAPH=0 keeps the eagerly enqueued data-parallel step
-    # (collectives issued per bucket from the backward pass on a communication stream).
-    if distributed and os.environ.get("BDETR_DP_GRAPH", "1") == "0":
+    # N > 1: the eagerly enqueued data-parallel step by default (collectives issued per bucket from the backward pass on a communication
+    # stream).  The CAPTURED data-parallel step - bucket all-reduces as nodes of the hipGraph chain, Model._graph_step - is an opt-in
+    # (--graph or BDETR_DP_GRAPH=1): it is rehearsed over a one-rank RCCL communicator (tests/test_dp_gpu.py) but has never run on more
+    # than one rank (no multi-GPU node was available to this build), eager and replayed steps measure the same at this configuration
+    # (launch probe: 25.2 against 25.5 ms), and a capture that fails on one of N ranks cannot be recovered from - the other ranks are
+    # inside their own capture of the same collectives - so it must not be what an unattended 8-GPU run meets first.  When opted in:
+    # every rank takes the decision from the same flags BEFORE any capture, no eager collective is issued between the eager set-up
+    # steps and the captured one (Model._graph_step drains the outstanding ones first), and a failed capture is fatal (exit code 3).
+    # (Round 4's watchdog abort - profiles/r04_sigabrt_capture_vs_rccl_watchdog.log - is fixed at its cause:
+    # engine.SegmentedCapture.CAPTURE_ERROR_MODE.)
+    if distributed and not args.graph and os.environ.get("BDETR_DP_GRAPH", "0") != "1":
         want_graph = False
     model.use_graph = want_graph and graph_ok
     graph_refused = want_graph and not graph_ok
@@ -389,7 +392,7 @@ def main():
             except Exception as exc:
                 if distributed:
                     print(f"[bench] rank {rank}: capture of the data-parallel step failed ({exc!r}); fatal under N > 1 "
-                          "(rerun with BDETR_DP_GRAPH=0 for the eagerly enqueued step)", file=sys.stderr, flush=True)
+                          "(the default at N > 1 is the eagerly enqueued step: drop --graph / BDETR_DP_GRAPH=1)", file=sys.stderr, flush=True)
                     os._exit(3)                             # (not sys.exit: the other ranks may be blocked in a captured collective's set-up)
                 raise
             torch.cuda.synchronize()
