@@ -242,14 +242,16 @@ def test_rccl_branch_runs_on_a_one_rank_communicator(cuda, tmp_path):
     print(p.stdout.strip().splitlines()[-1])
 
 
-def test_bench_multi_rank_code_path_over_one_rank_rccl(cuda):
+@pytest.mark.parametrize("launch", ["default", "graph"])
+def test_bench_multi_rank_code_path_over_one_rank_rccl(cuda, launch):
     """bench.py's N > 1 branch (nccl init with device_id, distribute(), barriers, max-over-ranks timing, per-bucket all-reduce
-    timing) on a one-rank RCCL communicator: the line must carry what the driver's 8-GPU run will be checked against."""
+    timing) on a one-rank RCCL communicator: the line must carry what the driver's 8-GPU run will be checked against.  "default" is
+    exactly what the driver launches at N > 1 - the eagerly enqueued data-parallel step (round 5) - "graph" the opt-in captured step."""
     import json
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port(), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", BDETR_DP_FORCE="1",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-roofline",
-                        "--no-batch32", "--no-fp32-policy", "--graph"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+                        "--no-batch32", "--no-fp32-policy"] + (["--graph"] if launch == "graph" else []), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert p.returncode == 0, (p.stdout[-2000:], "\n".join(l for l in p.stderr.splitlines() if not l.startswith("frame #"))[-6000:])
     line = json.loads(p.stdout.strip().splitlines()[-1])
     d = line["config"]["distributed"]
@@ -258,8 +260,8 @@ def test_bench_multi_rank_code_path_over_one_rank_rccl(cuda):
     ar = line["allreduce"]
     assert ar and ar["buckets_per_step"] >= 3 and 120e6 < ar["bytes_per_step"] < 130e6 and ar["allreduce_ms_per_step"] > 0, ar       # 31.0 M fp32 gradients
     assert line["range_guard"]["overflow_flag_after_run"] == 0 and line["range_guard"]["range_redos_in_timed_region"] == 0
-    assert line["value"] > 100 and line["config"]["step_launch"] == "hipGraph replay (segmented)"      # N > 1 takes the headline's launch path (round 4)
-    print({k: ar[k] for k in ("allreduce_ms_per_step", "algbw_GBps", "buckets_per_step")}, "images/s", line["value"])
+    assert line["value"] > 100 and line["config"]["step_launch"] == ("hipGraph replay (segmented)" if launch == "graph" else "eager"), line["config"]["step_launch"]
+    print(launch, {k: ar[k] for k in ("allreduce_ms_per_step", "algbw_GBps", "buckets_per_step")}, "images/s", line["value"])
 
 
 _WORKER_RCCL_GRAPH = r'''
