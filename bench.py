@@ -133,7 +133,7 @@ def hbm_traffic_per_launch():
 
 
 def _traffic_file():
-    for name in ("r04_gemm_hbm_traffic.json", "r03_gemm_hbm_traffic.json", "r02_gemm_hbm_traffic.json", "r01_igemm_hbm_traffic.json"):
+    for name in ("r05_gemm_hbm_traffic.json", "r04_gemm_hbm_traffic.json", "r03_gemm_hbm_traffic.json", "r02_gemm_hbm_traffic.json", "r01_igemm_hbm_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 return json.load(f), name
