@@ -97,7 +97,7 @@ SIGNATURES = {
     "bdetr_conv2d_bwd_weight_splitk": (I, [C.POINTER(ConvDesc)]),
     "bdetr_bn_apply_p16": (I, [P, P, P, P, P, P, I, C.POINTER(BnAffine), I, P, P, P, P, P, L, I, P]),
     "bdetr_bn_bwd_p16": (I, [P, P, I, P, P, P, P, P, I, I, P, P, P, P, P, P, P, P, I, L, I, P]),
-    "bdetr_bn_bwd_p16_even_pixels": (I, [P, P, I, P, P, P, P, P, I, I, P, P, P, P, P, P, I, I, I, I, P]),
+    "bdetr_bn_bwd_p16_even_pixels": (I, [P, P, I, P, P, P, P, P, I, I, P, P, P, P, P, P, I, I, I, I, I, P]),
     "bdetr_p16_supported": (I, [C.POINTER(ConvDesc)]),
     "bdetr_p16_pack": (I, [P, L, P, P, P, P]),
     "bdetr_p16_unpack": (I, [P, I, L, P, P]),
@@ -108,6 +108,7 @@ SIGNATURES = {
     "bdetr_p16_conv2d_bwd_data": (I, [P, P, P, C.POINTER(ConvDesc), I, P]),
     "bdetr_p16_conv2d_bwd_data_stat_chunks": (I, [C.POINTER(ConvDesc)]),
     "bdetr_p16_conv2d_bwd_data_masked_accum": (I, [P, P, P, P, C.POINTER(ConvDesc), C.POINTER(BnBwdFuse), P]),
+    "bdetr_p16_conv2d_bwd_data_masked_accum_compact": (I, [P, P, P, P, P, C.POINTER(ConvDesc), C.POINTER(BnBwdFuse), P]),
     "bdetr_relu_mask_apply": (I, [P, P, C.c_int64, P]),
     "bdetr_p16_conv2d_bwd_data_bnstats": (I, [P, P, P, C.POINTER(ConvDesc), C.POINTER(BnBwdFuse), P]),
     "bdetr_p16_conv2d_bwd_weight_splitk": (I, [C.POINTER(ConvDesc)]),

@@ -43,6 +43,10 @@ struct GemmParams {
     // ReLU mask of the element (norm.hip relu_mask_bits4 layout) - the skip branch of a residual unit merged without ever
     // materialising its masked gradient
     const unsigned long long* acc_mask;
+    // (round 5, with acc_mask; sgemm's EPI_COMPACT instantiation) the OLD gradient is not in C: it is the compact [N, acc_H/2, acc_W/2, J]
+    // tensor of the even pixels of an [N, acc_H, acc_W] map (what the stride-2 1x1 backward-data products of the next stage wrote) and
+    // zero everywhere else; C = product + old * bit is written to a fresh dense tensor
+    const float* acc_src; int acc_H, acc_W;
     // (sgemm's XX weight-gradient kernels) the B operand is stored as f16 pairs - the forward operand of the same convolution - and
     // is converted to bf16 pairs in registers after the fragment read, so that its producer need not write a bf16 copy at all
     int b_f16;
@@ -149,7 +153,7 @@ __device__ __forceinline__ unsigned mask_bits4(const unsigned long long* mask, i
 // statistics (above), then either LDS-transposed 16-byte row stores (store / accumulate) or per-element stores /
 // atomics (split-K).  `lds` must hold LDS_FLOATS >= BM * BN floats and be free to overwrite once every wave has
 // passed the barrier this function starts with.
-template <int BM, int BN, int WM, int WN, int NT, int LDS_FLOATS, bool MASKED_VARIANTS = false, bool BNB2_ONLY = false>
+template <int BM, int BN, int WM, int WN, int NT, int LDS_FLOATS, bool MASKED_VARIANTS = false, bool BNB2_ONLY = false, bool COMPACT_ONLY = false>
 __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], const GemmParams& g, float* lds,
                                               int tile_i, int i0, int j0, float* cbase, const float* bias_pre = nullptr) {
     constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
@@ -196,9 +200,11 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
         // still without its ReLU mask - C = product + old * bit (g.acc_mask) - and, with BNB, the ReLU decision of the fused sums
         // comes from g.bnb_mask instead of being recomputed.  Accumulate + sums together keep three float4 per row group alive
         // (product, old, y): that combination runs the tile in two halves so that it stays inside 256 VGPRs.
-        auto vec_out = [&](auto rowmap_c, auto accum_c, auto bnb_c, auto masked_c, auto bnb2_c) {
+        auto vec_out = [&](auto rowmap_c, auto accum_c, auto bnb_c, auto masked_c, auto bnb2_c, auto compact_c) {
             constexpr bool ROWMAP = decltype(rowmap_c)::value, ACCUM = decltype(accum_c)::value, BNB = decltype(bnb_c)::value, MASKED = decltype(masked_c)::value;
             constexpr bool BNB2 = decltype(bnb2_c)::value;         // + sum(g * xhat) of a second BatchNorm over the same g (bnb2_*)
+            constexpr bool COMPACT = decltype(compact_c)::value;   // the old gradient comes from g.acc_src (even pixels only), not from C
+            static_assert(!COMPACT || (ACCUM && MASKED && !ROWMAP && !BNB2), "the compact old gradient rides the masked accumulate");
             static_assert(!BNB2 || (BNB && ACCUM && MASKED), "the second BatchNorm rides the masked accumulate with masked sums");
             constexpr int NPART = (ACCUM && BNB) ? (BNB2 && ITERS % 4 == 0 ? 4 : 2) : 1, PIT = ITERS / NPART;
             static_assert(ITERS % NPART == 0, "the tile splits into equal parts");
@@ -231,7 +237,12 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
                     int64_t row = i;
                     if constexpr (ROWMAP) row = out_row(i);
                     dst[k] = cbase + row * g.ldc + jc;
-                    if constexpr (ACCUM) { old[k] = f32x4{0, 0, 0, 0}; if (ok[k]) old[k] = *reinterpret_cast<const f32x4*>(dst[k]); }
+                    if constexpr (ACCUM && COMPACT) {
+                        old[k] = f32x4{0, 0, 0, 0};
+                        const unsigned iu = (unsigned)i, w = iu % (unsigned)g.acc_W, t = iu / (unsigned)g.acc_W, h = t % (unsigned)g.acc_H, n = t / (unsigned)g.acc_H;
+                        if (ok[k] && ((h | w) & 1u) == 0u)
+                            old[k] = *reinterpret_cast<const f32x4*>(g.acc_src + ((int64_t)(n * (unsigned)(g.acc_H >> 1) + (h >> 1)) * (g.acc_W >> 1) + (w >> 1)) * g.ldc + jc);
+                    } else if constexpr (ACCUM) { old[k] = f32x4{0, 0, 0, 0}; if (ok[k]) old[k] = *reinterpret_cast<const f32x4*>(dst[k]); }
                     if constexpr (ACCUM && MASKED) { abits[k] = 0u; if (ok[k]) abits[k] = mask_bits4(g.acc_mask, (row * g.ldc + jc) >> 2); }
                     if constexpr (BNB) { yv[k] = f32x4{0, 0, 0, 0}; if (ok[k]) yv[k] = *reinterpret_cast<const f32x4*>(g.bnb_y + (int64_t)i * g.ldc + jc); }
                     if constexpr (BNB && MASKED) { bbits[k] = 0u; if (ok[k]) bbits[k] = mask_bits4(g.bnb_mask, ((int64_t)i * g.ldc + jc) >> 2); }
@@ -297,18 +308,23 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[BM / WM / 32][BN / W
         // host contracts: fused sums never come with a row map; a masked accumulate comes with masked sums or with none
         // (the second-BatchNorm form lives in a kernel instantiation of its own - sgemm.hip EPI_BNB2 - so that its extra float4 array
         // does not cost the other variants of the shared kernel registers: compiled in next to them it took their spills from 13 to 40)
-        if constexpr (BNB2_ONLY) { vec_out(F{}, T{}, T{}, T{}, T{}); return; }
+        if constexpr (BNB2_ONLY) { vec_out(F{}, T{}, T{}, T{}, T{}, F{}); return; }
+        if constexpr (COMPACT_ONLY) {               // (a kernel instantiation of its own, like BNB2_ONLY: sgemm.hip EPI_COMPACT)
+            if (g.bnb_y != nullptr) vec_out(F{}, T{}, T{}, T{}, F{}, T{});
+            else vec_out(F{}, T{}, F{}, T{}, F{}, T{});
+            return;
+        }
         if constexpr (MASKED_VARIANTS) {
             if (g.acc_mask != nullptr) {
-                if (g.bnb_y != nullptr) vec_out(F{}, T{}, T{}, T{}, F{});
-                else vec_out(F{}, T{}, F{}, T{}, F{});
+                if (g.bnb_y != nullptr) vec_out(F{}, T{}, T{}, T{}, F{}, F{});
+                else vec_out(F{}, T{}, F{}, T{}, F{}, F{});
                 return;
             }
         }
-        if (g.bnb_y != nullptr) vec_out(F{}, F{}, T{}, F{}, F{});
-        else if (g.rowmap) { if (accum) vec_out(T{}, T{}, F{}, F{}, F{}); else vec_out(T{}, F{}, F{}, F{}, F{}); }
-        else if (accum) vec_out(F{}, T{}, F{}, F{}, F{});
-        else vec_out(F{}, F{}, F{}, F{}, F{});
+        if (g.bnb_y != nullptr) vec_out(F{}, F{}, T{}, F{}, F{}, F{});
+        else if (g.rowmap) { if (accum) vec_out(T{}, T{}, F{}, F{}, F{}, F{}); else vec_out(T{}, F{}, F{}, F{}, F{}, F{}); }
+        else if (accum) vec_out(F{}, T{}, F{}, F{}, F{}, F{});
+        else vec_out(F{}, F{}, F{}, F{}, F{}, F{});
         return;
     }
     // per-element stores / accumulates / atomics (split-K, or rows that are not 16-byte aligned): the mode is hoisted too

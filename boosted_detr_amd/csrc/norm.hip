@@ -278,13 +278,17 @@ struct BnBwdFn {   // a = g (masked dout), b = g * xhat
     // even_h > 0: dout is zero outside the pixels (2i, 2j) of an [N, even_h, even_w] grid (it came out of the backward-data of stride-2
     // 1x1 convolutions): the reduction then runs over the N * ceil(H/2) * ceil(W/2) rows that can be non-zero, `r` counts those
     int even_h = 0, even_w = 0;
+    // dout_compact (with even_h > 0; round 5): dout is the COMPACT [N, ceil(H/2), ceil(W/2), C] tensor of those pixels alone - the stride-2
+    // backward-data products wrote it densely, no zero-filled [N, H, W, C] tensor exists - and `r` IS its row index
+    int dout_compact = 0;
     __device__ __forceinline__ void operator()(int64_t r, int c, f32x4& a, f32x4& b) const {
+        const int64_t rg = r;
         if (even_h > 0) {
             const unsigned w2 = (unsigned)(even_w + 1) >> 1, h2 = (unsigned)(even_h + 1) >> 1;
             const unsigned q = (unsigned)r, j2 = q % w2, t = q / w2, i2 = t % h2, n = t / h2;
             r = ((int64_t)n * even_h + 2 * i2) * even_w + 2 * j2;
         }
-        f32x4 g = *reinterpret_cast<const f32x4*>(dout + r * C + c);
+        f32x4 g = *reinterpret_cast<const f32x4*>(dout + (dout_compact ? rg : r) * C + c);
         f32x4 xv = *reinterpret_cast<const f32x4*>(x + r * C + c);
         f32x4 m = *reinterpret_cast<const f32x4*>(mean + c);
         f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + c);
@@ -596,7 +600,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_p16_kernel(const float* __re
                                                                const float* __restrict__ beta,
                                                                const float* __restrict__ dgamma, const float* __restrict__ dbeta, int relu, int frozen,
                                                                float* __restrict__ dx32, void* __restrict__ dx_bf16, float* __restrict__ dres,
-                                                               int64_t n4, int c4n, float inv_rows) {
+                                                               int64_t n4, int c4n, float inv_rows, int cH, int cW) {
+    // cH > 0 (round 5): dout is the compact [N, cH/2, cW/2, C] gradient of the even pixels of an [N, cH, cW] map (BnBwdFn::dout_compact);
+    // every other pixel's dout is zero - its dx is not (the mean terms), so the pass still visits every element
     // Same shape as bn_apply_p16_kernel: per-channel terms once per thread when the grid stride is a multiple of the channel count, two
     // row groups per trip with all their loads issued first.  The arithmetic is the unhoisted kernel's, operation for operation.
     const bool recompute = relu && out == nullptr;
@@ -613,7 +619,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_p16_kernel(const float* __re
     struct In { f32x4 g, xv, o; unsigned pm; };
     auto load_in = [&](int64_t i) {
         In q;
-        q.g = reinterpret_cast<const f32x4*>(dout)[i];
+        if (cH > 0) {
+            const unsigned iu = (unsigned)i, row = iu / (unsigned)c4n, cc = iu - row * (unsigned)c4n;      // (host: n4 < 2^32 in this mode)
+            const unsigned w = row % (unsigned)cW, t = row / (unsigned)cW, h = t % (unsigned)cH, n = t / (unsigned)cH;
+            q.g = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (((h | w) & 1u) == 0u) q.g = reinterpret_cast<const f32x4*>(dout)[((int64_t)(n * (unsigned)(cH >> 1) + (h >> 1)) * (cW >> 1) + (w >> 1)) * c4n + cc];
+        } else {
+            q.g = reinterpret_cast<const f32x4*>(dout)[i];
+        }
         q.xv = need_x ? reinterpret_cast<const f32x4*>(x)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
         q.o = f32x4{0.f, 0.f, 0.f, 0.f}; q.pm = 0u;
         if (relu && !recompute) {
@@ -1023,7 +1036,11 @@ extern "C" int bdetr_relu_mask_apply(float* x, const uint64_t* relu_mask, int64_
 static int bn_bwd_p16_impl(const float* dout, const void* out, int out_p16, const float* x, const float* mean,
                            const float* rstd, const float* gamma, const float* beta, int relu, int frozen,
                            float* dx32, void* dx_bf16, float* dgamma, float* dbeta, float* dresidual,
-                           float* ws, const float* pre_g, const float* pre_gx, int pre_n, int64_t rows, int C, int even_h, int even_w, void* stream) {
+                           float* ws, const float* pre_g, const float* pre_gx, int pre_n, int64_t rows, int C, int even_h, int even_w, void* stream,
+                           int dout_compact = 0) {
+    BDETR_CHECK_ARG(!dout_compact || (even_h > 0 && even_h % 2 == 0 && even_w % 2 == 0 && pre_g == nullptr && dresidual == nullptr),
+                    "bdetr_bn_bwd_p16_even_pixels: a compact dout needs an even map, the even-pixel reduction and no residual-gradient output");
+    BDETR_CHECK_ARG(!dout_compact || rows * C / 4 < ((int64_t)1 << 32), "bdetr_bn_bwd_p16_even_pixels: compact dout: more than 2^32 float4s");
     BDETR_CHECK_ARG(dout && x && mean && rstd && gamma && dx_bf16 && dgamma && dbeta && (ws || pre_g) && rows > 0 && C > 0 && C % 8 == 0,
                     "bdetr_bn_bwd_p16: bad arguments (C %% 8 == 0 required)");
     BDETR_CHECK_ARG((pre_g == nullptr) == (pre_gx == nullptr) && (pre_g == nullptr || pre_n > 0), "bdetr_bn_bwd_p16: pre_g / pre_gx / pre_n inconsistent");
@@ -1036,7 +1053,7 @@ static int bn_bwd_p16_impl(const float* dout, const void* out, int out_p16, cons
     if (pre_g != nullptr) {
         sum_partials2(pre_g, pre_gx, pre_n, C, dbeta, dgamma, st);
     } else {
-        BnBwdFn f{dout, reinterpret_cast<const float*>(out), x, mean, rstd, gamma, beta, C, relu, out_p16, even_h, even_w};
+        BnBwdFn f{dout, reinterpret_cast<const float*>(out), x, mean, rstd, gamma, beta, C, relu, out_p16, even_h, even_w, dout_compact};
         int64_t red_rows = rows;
         if (even_h > 0) {
             red_rows = rows / ((int64_t)even_h * even_w) * ((even_h + 1) / 2) * ((even_w + 1) / 2);
@@ -1049,7 +1066,7 @@ static int bn_bwd_p16_impl(const float* dout, const void* out, int out_p16, cons
     }
     const int64_t n4 = rows * C / 4;
     hipLaunchKernelGGL(bn_bwd_apply_p16_kernel, dim3(channel_aligned_grid(n4, C)), dim3(256), 0, st, dout, out, out_p16, x, mean, rstd, gamma, beta, dgamma, dbeta,
-                       relu, frozen, dx32, dx_bf16, dresidual, n4, C / 4, 1.0f / (float)rows);
+                       relu, frozen, dx32, dx_bf16, dresidual, n4, C / 4, 1.0f / (float)rows, dout_compact ? even_h : 0, dout_compact ? even_w : 0);
     return bdetr_launch_status("bn_bwd_p16");
 }
 
@@ -1064,10 +1081,10 @@ extern "C" int bdetr_bn_bwd_p16(const float* dout, const void* out, int out_p16,
 extern "C" int bdetr_bn_bwd_p16_even_pixels(const float* dout, const void* out, int out_p16, const float* x, const float* mean,
                                             const float* rstd, const float* gamma, const float* beta, int relu, int frozen,
                                             float* dx32, void* dx_bf16, float* dgamma, float* dbeta, float* dresidual,
-                                            float* ws, int N, int H, int W, int C, void* stream) {
+                                            float* ws, int N, int H, int W, int C, int dout_compact, void* stream) {
     BDETR_CHECK_ARG(N > 0 && H > 0 && W > 0 && ws && (int64_t)N * H * W < (int64_t)1 << 31, "bdetr_bn_bwd_p16_even_pixels: bad geometry");
     return bn_bwd_p16_impl(dout, out, out_p16, x, mean, rstd, gamma, beta, relu, frozen, dx32, dx_bf16, dgamma, dbeta, dresidual, ws, nullptr, nullptr, 0,
-                           (int64_t)N * H * W, C, H, W, stream);
+                           (int64_t)N * H * W, C, H, W, stream, dout_compact);
 }
 
 extern "C" int bdetr_add_dropout_layernorm_fwd(const float* x, const float* y, const float* gamma, const float* beta,

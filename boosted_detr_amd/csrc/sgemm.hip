@@ -200,7 +200,7 @@ constexpr int lds_bytes_for(int bm, int bn, int ns) { return ns * (bm + bn) * 12
 // runs.  The buffer descriptor covers exactly the tile's valid rows (rows past I are dropped by the buffer unit's range
 // check), a lane's column is valid or not for the whole tile (an invalid one starts 2 GB out of range), and the row
 // offset is one running VGPR: a store costs one add, and the second 32-column block rides the instruction's immediate.
-enum { EPI_PLAIN = 0, EPI_ROWMAP = 1, EPI_VEC = 8, EPI_BNB2 = 16 };      // EPI_BNB2 (with EPI_VEC): only the masked accumulate + masked sums + second-BatchNorm sum form
+enum { EPI_PLAIN = 0, EPI_ROWMAP = 1, EPI_VEC = 8, EPI_BNB2 = 16, EPI_COMPACT = 32 };      // EPI_COMPACT (with EPI_VEC): only the masked accumulate whose OLD gradient is a compact even-pixel tensor (GemmParams::acc_src)      // EPI_BNB2 (with EPI_VEC): only the masked accumulate + masked sums + second-BatchNorm sum form
 template <int BM, int BN, int WM, int WN, bool STATS = true, int EPI = EPI_ROWMAP>
 __device__ __forceinline__ void direct_epilogue(f32x16 (&acc)[BM / WM / 32][BN / WN / 32], const GemmParams& g, int tile_i, int i0, int j0, const float* bias_pre) {
     constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
@@ -757,7 +757,7 @@ void sgemm_kernel(typename LA::Op opa, typename LB::Op opb, GemmParams g)
             atomic_epilogue<BM, BN, WM, WN>(acc, g, i0, j0);
             return;
         }
-        gemm_epilogue<BM, BN, WM, WN, NT, LDS_BYTES / 4, (EPI & EPI_VEC) != 0, (EPI & EPI_BNB2) != 0>(acc, g, reinterpret_cast<float*>(lds), tile_i, i0, j0, g.c + (g.splitk > 1 ? (int64_t)zz * g.sc0 : 0), bias_pre);
+        gemm_epilogue<BM, BN, WM, WN, NT, LDS_BYTES / 4, (EPI & EPI_VEC) != 0, (EPI & EPI_BNB2) != 0, (EPI & EPI_COMPACT) != 0>(acc, g, reinterpret_cast<float*>(lds), tile_i, i0, j0, g.c + (g.splitk > 1 ? (int64_t)zz * g.sc0 : 0), bias_pre);
     }
 }
 
@@ -840,6 +840,11 @@ int launch_cfg(const typename LA::Op& a, const typename LB::Op& b, GemmParams g,
             BDETR_CHECK_ARG(g.vec_store, "sgemm: accumulate / fused BatchNorm-backward sums need 16-byte aligned C rows and J %% 4 == 0");
             BDETR_CHECK_ARG(g.acc_mask == nullptr || g.mode == ST_ACCUM, "sgemm: acc_mask without accumulate");
             BDETR_CHECK_ARG(g.bnb_mask == nullptr || (g.acc_mask != nullptr && g.bnb_y != nullptr), "sgemm: a bit-mask ReLU decision comes with a masked accumulate");
+            if (g.acc_src != nullptr) {
+                BDETR_CHECK_ARG(g.acc_mask != nullptr && g.bnb2_y == nullptr && g.acc_H > 0 && g.acc_W > 0 && g.acc_H % 2 == 0 && g.acc_W % 2 == 0 && g.I % (g.acc_H * g.acc_W) == 0,
+                                "sgemm: a compact old gradient needs the masked accumulate, an even map that divides the rows, and no second BatchNorm");
+                return go(std::integral_constant<int, EPI_VEC | EPI_COMPACT>{});
+            }
             if (g.bnb2_y != nullptr) return go(std::integral_constant<int, EPI_VEC | EPI_BNB2>{});
             return go(std::integral_constant<int, EPI_VEC>{});
         }
@@ -1010,7 +1015,7 @@ extern "C" int bdetr_p16_conv2d_bwd_data_stat_chunks(const bdetr_conv_desc* d) {
 // (bdetr_p16_pack_conv_weights); dx: fp32 [N,H,W,C].  bn (may be null): dx is the gradient of the BatchNorm(+ReLU) output
 // whose pre-normalisation tensor is bn->y - fuse that layer's backward reduction into this epilogue.
 static int p16_bwd_data(const void* dy_bf16, const void* wt_bf16, float* dx, const bdetr_conv_desc* d, int accumulate,
-                        const bdetr_bn_bwd_fuse* bn, const uint64_t* acc_mask, void* stream) {
+                        const bdetr_bn_bwd_fuse* bn, const uint64_t* acc_mask, void* stream, const float* acc_src = nullptr) {
     if (int e = check_conv(d, "bdetr_p16_conv2d_bwd_data")) return e;
     BDETR_CHECK_ARG(dy_bf16 && wt_bf16 && dx, "bdetr_p16_conv2d_bwd_data: null pointer");
     hipStream_t st = (hipStream_t)stream;
@@ -1018,6 +1023,7 @@ static int p16_bwd_data(const void* dy_bf16, const void* wt_bf16, float* dx, con
     GemmParams g; init_params(g);
     g.c = dx; g.ldc = d->C; g.mode = accumulate ? ST_ACCUM : ST_STORE;
     g.acc_mask = reinterpret_cast<const unsigned long long*>(acc_mask);
+    g.acc_src = acc_src; g.acc_H = d->H; g.acc_W = d->W;
     if (bn != nullptr) {
         const bool dense11 = d->R == 1 && d->S == 1 && d->pad == 0 && d->stride == 1;      // the persistent kernels' register epilogue
         BDETR_CHECK_ARG((!accumulate || dense11) && d->stride == 1 && d->C % 4 == 0 && aligned16(dx) && aligned16(bn->y),
@@ -1068,6 +1074,14 @@ extern "C" int bdetr_p16_conv2d_bwd_data_masked_accum(const void* dy_bf16, const
                     "bdetr_p16_conv2d_bwd_data_masked_accum: 1x1 stride-1 convolutions only, mask required");
     BDETR_CHECK_ARG((int64_t)d->N * d->H * d->W * d->C < (1LL << 32), "bdetr_p16_conv2d_bwd_data_masked_accum: more than 2^32 elements");
     return p16_bwd_data(dy_bf16, wt_bf16, dx, d, 1, bn, relu_mask, stream);
+}
+extern "C" int bdetr_p16_conv2d_bwd_data_masked_accum_compact(const void* dy_bf16, const void* wt_bf16, float* dx, const float* old_even,
+                                                              const uint64_t* relu_mask, const bdetr_conv_desc* d, const bdetr_bn_bwd_fuse* bn, void* stream) {
+    BDETR_CHECK_ARG(relu_mask != nullptr && old_even != nullptr && d != nullptr && d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0 && d->H % 2 == 0 && d->W % 2 == 0,
+                    "bdetr_p16_conv2d_bwd_data_masked_accum_compact: 1x1 stride-1 convolutions on an even map only; mask and old gradient required");
+    BDETR_CHECK_ARG((int64_t)d->N * d->H * d->W * d->C < (1LL << 32) && aligned16(old_even) && (bn == nullptr || bn->y2 == nullptr),
+                    "bdetr_p16_conv2d_bwd_data_masked_accum_compact: more than 2^32 elements, a misaligned old gradient, or a second BatchNorm");
+    return p16_bwd_data(dy_bf16, wt_bf16, dx, d, 1, bn, relu_mask, stream, old_even);
 }
 extern "C" int bdetr_p16_conv2d_bwd_data_bnstats(const void* dy_bf16, const void* wt_bf16, float* dx,
                                                  const bdetr_conv_desc* d, const bdetr_bn_bwd_fuse* bn, void* stream) {

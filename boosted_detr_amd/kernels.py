@@ -370,7 +370,7 @@ def bn_apply_p16(x2d, mean, rstd, gamma, beta, residual=None, relu=False, want_f
 
 
 def bn_bwd_p16(dout, out, x2d, mean, rstd, gamma, relu, frozen, want_residual_grad=False, dgamma=None, dbeta=None, beta=None, want_fp32=False,
-               out_p16=False, pre=None, even_pixels=None):
+               out_p16=False, pre=None, even_pixels=None, dout_compact=False):
     """bn_bwd writing the input gradient as a bf16 pair: returns (dx_bf16, dx32 | None, dgamma, dbeta, dres | None).
     out_p16: what the ReLU mask source `out` is - 0 / False the fp32 forward output, 1 / True its bf16 pair copy, 2 the bit
     mask of bn_apply_p16(want_mask=True)."""
@@ -390,9 +390,12 @@ def bn_bwd_p16(dout, out, x2d, mean, rstd, gamma, relu, frozen, want_residual_gr
         # dout [N,H,W,C] is zero outside the pixels (2i, 2j) (ops.conv_bn tags such gradients): the reduction visits those only
         N, H, W = even_pixels
         assert N * H * W == rows
+        # dout_compact: dout is the [N, H/2, W/2, C] tensor of the even pixels alone (the stride-2 backward-data products wrote it densely)
+        assert not dout_compact or (dres is None and dout.numel() == N * (H // 2) * (W // 2) * Cc and H % 2 == 0 and W % 2 == 0)
         check(L.bdetr_bn_bwd_p16_even_pixels(_p(dout), _p(out), int(out_p16), _p(x2d), _p(mean), _p(rstd), _p(gamma), _p(beta), int(relu), int(frozen),
-                                             _p(dx32), _p(dxb), _p(dgamma), _p(dbeta), _p(dres), _p(ws), N, H, W, Cc, _stream()), "bn_bwd_p16_even_pixels")
+                                             _p(dx32), _p(dxb), _p(dgamma), _p(dbeta), _p(dres), _p(ws), N, H, W, Cc, int(dout_compact), _stream()), "bn_bwd_p16_even_pixels")
         return dxb, dx32, dgamma, dbeta, dres
+    assert not dout_compact, "a compact dout goes through the even-pixel reduction (even_pixels=(N, H, W), no pre)"
     pg, pgx, pn = pre if pre is not None else (None, None, 0)
     check(L.bdetr_bn_bwd_p16(_p(dout), _p(out), int(out_p16), _p(x2d), _p(mean), _p(rstd), _p(gamma), _p(beta), int(relu), int(frozen), _p(dx32),
                              _p(dxb), _p(dgamma), _p(dbeta), _p(dres), _p(ws), _p(pg), _p(pgx), int(pn), rows, Cc, _stream()), "bn_bwd_p16")
@@ -440,7 +443,7 @@ def relu_mask_apply_(x: torch.Tensor, relu_mask: torch.Tensor) -> torch.Tensor:
     return x
 
 
-def p16_conv2d_bwd_data_masked_accum(dy_bf16, wt_bf16, g: ConvGeom, dx: torch.Tensor, relu_mask: torch.Tensor, bn_ctx=None, bn_ctx2=None):
+def p16_conv2d_bwd_data_masked_accum(dy_bf16, wt_bf16, g: ConvGeom, dx: torch.Tensor, relu_mask: torch.Tensor, bn_ctx=None, bn_ctx2=None, old_even=None):
     """dx (the gradient of a residual unit's output on entry) <- conv_transpose(dy) + dx * relu_mask, in place: the unit's skip
     branch merged inside the 1x1 backward-data epilogue of its first convolution.  bn_ctx = (y_prev, mean, rstd, gamma, beta,
     relu_mask_prev): the result is the complete output gradient of the PREVIOUS residual unit - also emit that unit's
@@ -449,9 +452,20 @@ def p16_conv2d_bwd_data_masked_accum(dy_bf16, wt_bf16, g: ConvGeom, dx: torch.Te
     _chk(relu_mask, dtype=torch.int64)
     L = _lib.lib()
     d = g.desc()
+    if old_even is not None:
+        # the unit's output gradient exists at the even pixels only: old_even [N, H/2, W/2, C] (compact), dx is a FRESH dense tensor
+        _chk(old_even)
+        assert bn_ctx2 is None and old_even.numel() * 4 == dx.numel() and g.H % 2 == 0 and g.W % 2 == 0
+
+        def launch(fuse):
+            check(L.bdetr_p16_conv2d_bwd_data_masked_accum_compact(_p(dy_bf16), _p(wt_bf16), _p(dx), _p(old_even), _p(relu_mask), C.byref(d), fuse, _stream()),
+                  "p16_conv2d_bwd_data_masked_accum_compact")
+    else:
+        def launch(fuse):
+            check(L.bdetr_p16_conv2d_bwd_data_masked_accum(_p(dy_bf16), _p(wt_bf16), _p(dx), _p(relu_mask), C.byref(d), fuse, _stream()),
+                  "p16_conv2d_bwd_data_masked_accum")
     if bn_ctx is None:
-        check(L.bdetr_p16_conv2d_bwd_data_masked_accum(_p(dy_bf16), _p(wt_bf16), _p(dx), _p(relu_mask), C.byref(d), None, _stream()),
-              "p16_conv2d_bwd_data_masked_accum")
+        launch(None)
         return dx
     y_prev, mean, rstd, gamma, beta, bits_prev = bn_ctx
     _chk(y_prev, mean, rstd, gamma, beta)
@@ -469,8 +483,7 @@ def p16_conv2d_bwd_data_masked_accum(dy_bf16, wt_bf16, g: ConvGeom, dx: torch.Te
         _chk(y0, mean0, rstd0)
         pgx2 = empty(n, g.C, like=dy_bf16)
         f.y2, f.mean2, f.rstd2, f.part_gx2 = _p(y0), _p(mean0), _p(rstd0), _p(pgx2)
-    check(L.bdetr_p16_conv2d_bwd_data_masked_accum(_p(dy_bf16), _p(wt_bf16), _p(dx), _p(relu_mask), C.byref(d), C.byref(f), _stream()),
-          "p16_conv2d_bwd_data_masked_accum")
+    launch(C.byref(f))
     if pgx2 is not None:
         return dx, (pg, pgx, n), (pg, pgx2, n)
     return dx, (pg, pgx, n)

@@ -204,7 +204,9 @@ int bdetr_bn_bwd_p16(const float* dout, const void* out, int out_p16, const floa
 int bdetr_bn_bwd_p16_even_pixels(const float* dout, const void* out, int out_p16, const float* x, const float* mean,
                                  const float* rstd, const float* gamma, const float* beta, int relu, int frozen,
                                  float* dx32, void* dx_bf16, float* dgamma, float* dbeta, float* dresidual,
-                                 float* ws, int N, int H, int W, int C, void* stream);
+                                 float* ws, int N, int H, int W, int C,
+                                 int dout_compact /* ABI 7: dout is the compact [N, H/2, W/2, C] tensor of those pixels alone (H, W even;
+                                 dresidual must be null): see bdetr_p16_conv2d_bwd_data_masked_accum_compact */, void* stream);
 int bdetr_p16_supported(const bdetr_conv_desc* d);
 int bdetr_p16_pack(const float* x, int64_t n, void* f16_out, void* bf16_out, int* overflow_flag, void* stream);
 int bdetr_p16_unpack(const void* p, int is_f16, int64_t n, float* out, void* stream);
@@ -248,6 +250,12 @@ int bdetr_relu_mask_apply(float* x, const uint64_t* relu_mask, int64_t n, void* 
 int bdetr_p16_conv2d_bwd_data_masked_accum(const void* dy_bf16, const void* wt_bf16, float* dx, const uint64_t* relu_mask,
                                            const bdetr_conv_desc* d, const bdetr_bn_bwd_fuse* bn /* may be null: the BatchNorm-backward
                                            sums of the unit whose output gradient this launch completes */, void* stream);
+/* (ABI 7) The same merge when the unit's output gradient exists only at the even pixels: old_even is the COMPACT fp32
+ * [N, H/2, W/2, C] tensor that the stride-2 1x1 backward-data products of the next stage wrote densely (Keras: the stride-2 conv1 and
+ * projection shortcut of the next stage's first block, reference backbone.py:37-38), zero everywhere else - no zero-filled dense
+ * gradient is ever written.  dx (fp32 [N,H,W,C], uninitialised on entry) = conv_transpose(dy) + expand(old_even) * relu_mask. */
+int bdetr_p16_conv2d_bwd_data_masked_accum_compact(const void* dy_bf16, const void* wt_bf16, float* dx, const float* old_even,
+                                                   const uint64_t* relu_mask, const bdetr_conv_desc* d, const bdetr_bn_bwd_fuse* bn, void* stream);
 int bdetr_p16_conv2d_bwd_data_bnstats(const void* dy_bf16, const void* wt_bf16, float* dx,
                                       const bdetr_conv_desc* d, const bdetr_bn_bwd_fuse* bn, void* stream);
 /* dw fp32 [K][R][S][C] += sum over pixels of dy x patches(x); with splitk > 1 the slices add with float

@@ -402,3 +402,44 @@ def test_stride2_backward_data_gradients_carry_the_even_pixel_tag(cuda):
     off = sparse.clone()
     off[:, ::2, ::2] = 0
     assert float(off.abs().max()) == 0.0 and float(sparse.abs().max()) > 0
+
+
+@pytest.mark.parametrize("N,H,W,C,K", [(2, 20, 20, 64, 256), (3, 8, 12, 256, 64), (16, 40, 40, 1024, 256)])
+def test_compact_even_pixel_gradient_through_masked_accumulate_and_batchnorm_backward(cuda, N, H, W, C, K):
+    """Round 5: the gradient of a stage's last unit reaches it only through the next stage's stride-2 1x1 convolutions, i.e. at the pixels
+    (2i, 2j).  It now exists as the COMPACT [N, H/2, W/2, C] tensor those products write densely - no zero-filled [N, H, W, C] tensor - and
+    its two consumers read it through the pixel map: bdetr_p16_conv2d_bwd_data_masked_accum_compact (the unit's skip merge, into a fresh
+    dense tensor, with and without the previous unit's fused BatchNorm sums) and bdetr_bn_bwd_p16_even_pixels(dout_compact=1).  Both must
+    equal the dense-gradient forms bit for bit (same arithmetic, same summation order)."""
+    from boosted_detr_amd import kernels as k
+    g = k.ConvGeom(N, H, W, C, K, 1, 1, 1, 0)
+    rows = N * H * W
+
+    def unit(seed):
+        y = dev(rnd(rows, C, seed=seed) * 2 + 0.3)
+        gamma, beta = dev(1 + 0.1 * rnd(C, seed=seed + 1)), dev(0.1 * rnd(C, seed=seed + 2))
+        mean, rstd = k.bn_stats(rows, C, k.colstats(y), 1.001e-5, 0.99, True, dev(torch.zeros(C)), dev(torch.ones(C)), like=y)
+        _, _, _, bits = k.bn_apply_p16(y, mean, rstd, gamma, beta, dev(rnd(rows, C, seed=seed + 3)), True, want_fp32=False, want_f16=True,
+                                       want_bf16=False, want_mask=True)
+        return y, mean, rstd, gamma, beta, bits
+
+    prev, this = unit(10), unit(20)
+    compact = rnd(N, H // 2, W // 2, C, seed=5)
+    dense = torch.zeros(N, H, W, C)
+    dense[:, ::2, ::2] = compact
+    _, wt = k.p16_pack_conv_weights(dev(rnd(K, 1, 1, C, seed=6, scale=C ** -0.5)), want_fwd=False)
+    _, dyb = k.p16_pack(dev(rnd(N, H, W, K, seed=7)), want_f16=False)
+    # the skip merge
+    want = k.p16_conv2d_bwd_data_masked_accum(dyb, wt, g, dev(dense), this[5])
+    got = k.p16_conv2d_bwd_data_masked_accum(dyb, wt, g, torch.empty(N, H, W, C, device="cuda"), this[5], old_even=dev(compact))
+    assert torch.equal(got, want)
+    want2, parts_w = k.p16_conv2d_bwd_data_masked_accum(dyb, wt, g, dev(dense), this[5], bn_ctx=prev)
+    got2, parts_g = k.p16_conv2d_bwd_data_masked_accum(dyb, wt, g, torch.empty(N, H, W, C, device="cuda"), this[5], bn_ctx=prev, old_even=dev(compact))
+    assert torch.equal(got2, want) and torch.equal(want2, want)
+    assert torch.equal(parts_g[0], parts_w[0]) and torch.equal(parts_g[1], parts_w[1]) and parts_g[2] == parts_w[2]
+    # the unit's own BatchNorm backward (ReLU decision = its bit mask): reduction over the even pixels, apply over every pixel
+    y, mean, rstd, gamma, beta, bits = this
+    ref = k.bn_bwd_p16(dev(dense).view(rows, C), bits, y, mean, rstd, gamma, True, False, beta=beta, want_fp32=True, out_p16=2, even_pixels=(N, H, W))
+    cmp_ = k.bn_bwd_p16(dev(compact).view(-1, C), bits, y, mean, rstd, gamma, True, False, beta=beta, want_fp32=True, out_p16=2, even_pixels=(N, H, W),
+                        dout_compact=True)
+    assert torch.equal(cmp_[0], ref[0]) and torch.equal(cmp_[1], ref[1]) and torch.equal(cmp_[2], ref[2]) and torch.equal(cmp_[3], ref[3])
