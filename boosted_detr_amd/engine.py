@@ -182,6 +182,19 @@ def materialise(g):
     """A gradient tensor tagged ``_lazy_mask`` stands for tensor * mask (the skip gradient of a residual unit, handed on
     without applying the unit's ReLU bit mask: ops.conv_bn).  Ops that know the tag fold the mask into their own kernel;
     for everybody else the mask is applied in place here."""
+    c = getattr(g, "_compact_even", None) if g is not None else None
+    if c is not None:
+        # A gradient that exists at the pixels (2i, 2j) only, held as the compact [N, H/2, W/2, C] tensor the stride-2 backward-data
+        # products wrote (ops.conv_bn).  Its two regular consumers read it through the pixel map; anybody else gets the dense
+        # zero-filled tensor, built here (a torch strided copy: the fallback, not the step's path) - a NEW tensor: callers re-bind.
+        N, H, W = c
+        d = torch.zeros(N, H, W, g.shape[-1], dtype=g.dtype, device=g.device)
+        d[:, ::2, ::2] = g.view(N, H // 2, W // 2, g.shape[-1])
+        d._bdetr_owned = True
+        d._even_pixels = (N, H, W)
+        if getattr(g, "_lazy_mask", None) is not None:
+            d._lazy_mask = g._lazy_mask
+        g = d
     m = getattr(g, "_lazy_mask", None)
     if m is not None:
         K.relu_mask_apply_(g, m)
@@ -229,7 +242,12 @@ class Tape:
                     have = grads[key]
                     if acc is not None and acc[i] is not None and g is acc[i]:
                         continue                                    # the op already accumulated into the offered tensor
+                    if acc is not None and acc[i] is not None and getattr(g, "_replaces_acc", False):
+                        del g._replaces_acc                         # ... or folded it into a fresh tensor (a compact even-pixel gradient merged into a dense one)
+                        grads[key] = g
+                        continue
                     g, have = materialise(g), materialise(have)
+                    grads[key] = have                               # (materialise re-binds a compact even-pixel tensor to its dense form)
                     # partial sums that rode in with `have` (a BatchNorm-backward reduction fused into the epilogue that
                     # produced it: ops.conv_bn) describe the tensor BEFORE this contribution: drop them
                     if hasattr(have, "_bnb_parts"):

@@ -118,6 +118,9 @@ def image_prep(image: torch.Tensor, H: int, W: int) -> torch.Tensor:
     return K.image_prep(image, H, W)     # input images need no gradient
 
 
+COMPACT_S2 = os.environ.get("BDETR_COMPACT_S2", "1") != "0"       # stride-2 1x1 input gradients as compact even-pixel tensors (conv_bn backward)
+
+
 class BNState:
     """gamma/beta/moving stats of one BatchNormalization layer + its hyper-parameters."""
 
@@ -299,11 +302,20 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
         out = out2d.view(N, g.OH, g.OW, Kout)
 
     def backward(g_out, acc=None):
+        want_res = residual is not None
+        # A gradient that exists at the pixels (2i, 2j) only arrives as the compact [N, OH/2, OW/2, K] tensor its producers - the next
+        # stage's stride-2 1x1 backward-data products, below - wrote densely (round 5: no zero-filled dense tensor, no scatter).  A
+        # residual unit on the pre-split path reads it through the pixel map in both of its consumers (this BatchNorm backward and
+        # the skip merge of the unit's first convolution); every other case gets the dense form (engine.materialise).
+        compact = getattr(g_out, "_compact_even", None)
+        if compact is not None and not (p16 and _p16_active() and relu and want_res and relu_bits is not None and LAZY_SKIP and compact == (N, g.OH, g.OW)
+                                         and getattr(g_out, "_bdetr_owned", False) and getattr(g_out, "_lazy_mask", None) is None
+                                         and getattr(g_out, "_bnb_parts", None) is None and g_out.is_contiguous()):
+            g_out, compact = materialise(g_out), None
         lazy_bits = getattr(g_out, "_lazy_mask", None)      # g_out still needs its producer's ReLU mask (see below)
         if lazy_bits is not None and not (p16 and _p16_active() and not relu and residual is None):
             g_out, lazy_bits = materialise(g_out), None
         g2d = _2d(g_out.contiguous())
-        want_res = residual is not None
         if p16 and _p16_active():
             sg, sb = GradSink(bn.gamma), GradSink(bn.beta)
             # ReLU mask: recomputed from y when there is no residual, else read from the forward output (fp32, or the
@@ -327,11 +339,15 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
             even = getattr(g_out, "_even_pixels", None) if EVEN_PIXELS else None     # zero off the even pixels: a quarter-size reduction pass
             if even is not None and even != (N, g.OH, g.OW):
                 even = None
+            if compact is not None:
+                assert lazy_skip and pre is None, "a compact even-pixel gradient is handed on to the skip merge as it is"
+                even = compact
             dyb, _, _, _, dres = K.bn_bwd_p16(g2d, mask_src, y2d, mean, rstd, bn.gamma.value, bn_relu, False,
                                               want_residual_grad=want_res and not lazy_skip,
-                                              dgamma=sg.buf, dbeta=sb.buf, beta=bn.beta.value, out_p16=mode, pre=pre, even_pixels=even)
+                                              dgamma=sg.buf, dbeta=sb.buf, beta=bn.beta.value, out_p16=mode, pre=pre, even_pixels=even,
+                                              dout_compact=compact is not None)
             if lazy_skip:
-                dres = _own(g_out.view(residual.shape))
+                dres = _own(g_out.view(residual.shape)) if compact is None else _own(g_out)      # (compact: keeps its `_compact_even` tag)
                 dres._lazy_mask = relu_bits
                 sc_parts = getattr(g_out, "_bnb_parts_shortcut", None)
                 if sc_parts is not None and res_bn is not None:
@@ -355,10 +371,36 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
                 side_task(param_grads, xw, dyb)
             dx = None
             s2 = R == 1 and S == 1 and stride == 2 and pad == 0
+            # a stride-2 1x1 convolution's input gradient lives at the pixels (2i, 2j): on an even map it is produced as the compact
+            # [N, H/2, W/2, C] tensor - a plain dense product over the OUTPUT grid - and tagged; see the top of this function
+            s2c = s2 and COMPACT_S2 and H % 2 == 0 and W % 2 == 0
+            gc = K.ConvGeom(N, g.OH, g.OW, Cin, Kout, 1, 1, 1, 0) if s2c else None
             if x_needs_grad:
                 _, wt = packed_weights(w, need_bwd=True)
                 ctx = getattr(x_handle, "_bn_ctx", None)
-                if acc is not None and acc[0] is not None:
+                have_c = getattr(acc[0], "_compact_even", None) if acc is not None and acc[0] is not None else None
+                if have_c is not None and s2c and have_c == (N, H, W) and getattr(acc[0], "_lazy_mask", None) is None:
+                    # the other stride-2 consumer of x was first: add into its compact tensor
+                    K.p16_conv2d_bwd_data(dyb4, wt, gc, dx=acc[0].view(N, g.OH, g.OW, Cin), accumulate=True)
+                    dx = acc[0]
+                elif have_c is not None and getattr(acc[0], "_lazy_mask", None) is not None and R == 1 and S == 1 and stride == 1 and pad == 0 \
+                        and have_c == (N, H, W) and getattr(x_handle, "_bn_ctx_bits2", None) is None:
+                    # the skip merge of a stage's last unit: conv_transpose(dy) + expand(compact gradient) * mask into a FRESH dense tensor
+                    ctx_bits = getattr(x_handle, "_bn_ctx_bits", None)
+                    fresh = K.empty(N, H, W, Cin, like=dyb)
+                    r = K.p16_conv2d_bwd_data_masked_accum(dyb4, wt, g, fresh, acc[0]._lazy_mask, bn_ctx=ctx_bits, old_even=acc[0])
+                    dx = _own(fresh)
+                    if ctx_bits is not None:
+                        dx._bnb_parts = r[1]
+                    dx._replaces_acc = True                 # (engine.Tape: this tensor IS the accumulated gradient now)
+                elif have_c is not None:
+                    base = materialise(acc[0])              # any other pairing: the dense form (a new tensor), then the plain accumulate
+                    K.p16_conv2d_bwd_data(dyb4, wt, g, dx=base.view(N, H, W, Cin), accumulate=True)
+                    if hasattr(base, "_even_pixels") and not (s2 and base._even_pixels == (N, H, W)):
+                        del base._even_pixels
+                    dx = base
+                    dx._replaces_acc = True
+                elif acc is not None and acc[0] is not None:
                     skip_bits = getattr(acc[0], "_lazy_mask", None)
                     if skip_bits is not None and R == 1 and S == 1 and stride == 1 and pad == 0:
                         ctx_bits = getattr(x_handle, "_bn_ctx_bits", None)
@@ -380,6 +422,9 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
                     dx, parts = K.p16_conv2d_bwd_data_bnstats(dyb4, wt, g, *ctx)
                     dx = _own(dx)
                     dx._bnb_parts = parts
+                elif s2c:
+                    dx = _own(K.p16_conv2d_bwd_data(dyb4, wt, gc))
+                    dx._compact_even = (N, H, W)
                 else:
                     dx = _own(K.p16_conv2d_bwd_data(dyb4, wt, g))
                     if s2:

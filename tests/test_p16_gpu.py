@@ -377,28 +377,44 @@ def test_bn_backward_reduces_over_the_even_pixels_of_a_strided_gradient(cuda, N,
 
 
 def test_stride2_backward_data_gradients_carry_the_even_pixel_tag(cuda):
-    """Two stride-2 1x1 consumers of one tensor (the next stage's c1 and projection shortcut): the accumulated input gradient keeps
-    the tag and IS zero off the even pixels; a dense contribution drops it."""
+    """Two stride-2 1x1 consumers of one tensor (the next stage's c1 and projection shortcut).  Round 5: on an even map their accumulated
+    input gradient is the COMPACT [N, H/2, W/2, C] tensor of the pixels (2i, 2j), tagged `_compact_even`; engine.materialise turns it into
+    the dense zero-filled tensor (tag `_even_pixels`), which equals what the scatter form (BDETR_COMPACT_S2 off) writes, bit for bit; a
+    dense contribution from a third consumer yields an untagged dense gradient with the same values either way."""
     from boosted_detr_amd import kernels as k, ops
     from boosted_detr_amd.backbone import _ConvBN
-    from boosted_detr_amd.engine import Tape, join_side_stream, recording
+    from boosted_detr_amd.engine import Tape, join_side_stream, materialise, recording
     N, H, C = 2, 12, 64
     a, b, d = (_ConvBN("t/", f"c{i}", f"b{i}", C, 128, 1, s, 0, seed=i) for i, s in ((1, 2), (2, 2), (3, 1)))
     x32 = dev(rnd(N, H, H, C, seed=1)).relu_()
     seen = {}
-    with k.gemm_precision("split"):
-        for layers in ((a, b), (d, a, b)):
-            x = x32.clone()
-            xf, _ = k.p16_pack(x, want_f16=True, want_bf16=False)
-            x._p16f, x._p16b = xf, None
-            tape = Tape()
-            with recording(tape):
-                outs = [l([x], training=True, relu=True, want_fp32=True) for l in layers]
-            grads = tape.backward({id(o): dev(rnd(*o.shape, seed=7 + i)) for i, o in enumerate(outs)})
-            join_side_stream()
-            seen[len(layers)] = grads[id(x)]
-    sparse, dense = seen[2], seen[3]
-    assert getattr(sparse, "_even_pixels", None) == (N, H, H) and not hasattr(dense, "_even_pixels")
+    keep = ops.COMPACT_S2
+    try:
+        with k.gemm_precision("split"):
+            for compact in (True, False):
+                ops.COMPACT_S2 = compact
+                for layers in ((a, b), (d, a, b), (a, b, d)):
+                    x = x32.clone()
+                    xf, _ = k.p16_pack(x, want_f16=True, want_bf16=False)
+                    x._p16f, x._p16b = xf, None
+                    tape = Tape()
+                    with recording(tape):
+                        outs = [l([x], training=True, relu=True, want_fp32=True) for l in layers]
+                    seeds = {l: dev(rnd(*o.shape, seed=7 + (a, b, d).index(l))) for l, o in zip(layers, outs)}
+                    grads = tape.backward({id(o): seeds[l] for l, o in zip(layers, outs)})
+                    join_side_stream()
+                    seen[(compact, layers)] = grads[id(x)]
+    finally:
+        ops.COMPACT_S2 = keep
+    c2, s2 = seen[(True, (a, b))], seen[(False, (a, b))]
+    assert getattr(c2, "_compact_even", None) == (N, H, H) and tuple(c2.shape) == (N, H // 2, H // 2, C)
+    assert getattr(s2, "_even_pixels", None) == (N, H, H) and tuple(s2.shape) == (N, H, H, C)
+    sparse = materialise(c2)
+    assert getattr(sparse, "_even_pixels", None) == (N, H, H) and not hasattr(sparse, "_compact_even") and torch.equal(sparse, s2)
+    for order in ((d, a, b), (a, b, d)):            # the dense consumer processed last / first in the backward pass
+        dc, ds = seen[(True, order)], seen[(False, order)]
+        assert not hasattr(dc, "_even_pixels") and not hasattr(dc, "_compact_even") and not hasattr(ds, "_even_pixels")
+        close(dc, ds, rtol=1e-6)
     off = sparse.clone()
     off[:, ::2, ::2] = 0
     assert float(off.abs().max()) == 0.0 and float(sparse.abs().max()) > 0
