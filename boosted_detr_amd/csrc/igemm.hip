@@ -980,11 +980,16 @@ extern "C" int bdetr_conv2d_bwd_weight_splitk(const bdetr_conv_desc* d) {
     TileChoice t = choose_tile(d->K, Kd, 2, false, use_split(true) != AR_FP32, !(d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0));
     int64_t tiles = cdiv64(d->K, t.bm) * cdiv64(Kd, t.bn);
     int64_t want = 3LL * num_cus();
+    // A handful of output tiles over a very long pixel range - the stem's 64 x 196 gradient over 1.6 M pixels, the LAST kernel of the
+    // backward pass, alone on the chip with the optimizer waiting for it: 16 workgroups per CU instead of 3 (tools/stem_wgrad_probe.py,
+    // round 5: split 192 -> 467 us, 1024 -> 355 us)
+    const bool few_tiles = tiles <= 8;
+    if (few_tiles) want = 16LL * num_cus();
     int64_t sk = cdiv64(want, tiles);
     int64_t maxsk = cdiv64(M, 4 * BK);      // keep >= 4 stages per split
     if (sk > maxsk) sk = maxsk;
     if (sk < 1) sk = 1;
-    if (sk > 512) sk = 512;
+    if (sk > (few_tiles ? 1024 : 512)) sk = few_tiles ? 1024 : 512;
     return (int)sk;
 }
 

@@ -22,7 +22,12 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const uint64_t* __restrict_
     const float* g = reinterpret_cast<const float*>(ptrs[3 * t + 1]);
     const int64_t n = sizes[t];
     float s = 0.f;
-    for (int64_t i = off + threadIdx.x; i < min(n, off + SLAB); i += 256) { float x = g[i]; s += x * x; }
+    // 16-byte loads over the slab's whole quads (every tensor's slot in the flat buffers is 16-byte aligned and a slab starts at a
+    // multiple of 16,384 elements), the last 1-3 elements one by one: the 4-byte form ran at 2.1 TB/s (round 5)
+    const int64_t end = min(n, off + SLAB), nq = (reinterpret_cast<uintptr_t>(g) & 15) == 0 ? (end - off) >> 2 : 0;
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(g + off);
+    for (int64_t q = threadIdx.x; q < nq; q += 256) { const f32x4 x = g4[q]; s += x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3]; }
+    for (int64_t i = off + 4 * nq + threadIdx.x; i < end; i += 256) { float x = g[i]; s += x * x; }
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -59,7 +64,23 @@ __global__ __launch_bounds__(256) void sgd_apply_kernel(const uint64_t* __restri
         const float nrm = norms[t] * fabsf(grad_scale);
         if (nrm > clipnorm) scale *= clipnorm / nrm;
     }
-    for (int64_t i = off + threadIdx.x; i < min(n, off + SLAB); i += 256) {
+    const bool aligned = ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(w)) & 15) == 0;
+    const int64_t end = min(n, off + SLAB), nq = aligned ? (end - off) >> 2 : 0;
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(g + off);
+    f32x4* v4 = reinterpret_cast<f32x4*>(v + off);
+    f32x4* w4 = reinterpret_cast<f32x4*>(w + off);
+    for (int64_t q = threadIdx.x; q < nq; q += 256) {             // (the same arithmetic per element as the scalar tail below)
+        const f32x4 gq = g4[q], vq = v4[q], wq = w4[q];
+        f32x4 vn, wn;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gi = gq[e] * scale;
+            vn[e] = momentum * vq[e] - lr * gi;
+            wn[e] = wq[e] + momentum * vn[e] - lr * gi;
+        }
+        v4[q] = vn; w4[q] = wn;
+    }
+    for (int64_t i = off + 4 * nq + threadIdx.x; i < end; i += 256) {
         const float gi = g[i] * scale;
         const float vn = momentum * v[i] - lr * gi;
         v[i] = vn;
