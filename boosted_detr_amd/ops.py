@@ -546,7 +546,11 @@ def conv_bn_relu_maxpool(x: torch.Tensor, w: Variable, b: Variable, bn: BNState,
         parts = K.colstats(_2d(y))
     mean, rstd = K.bn_stats(g.M, Kout, parts, bn.eps, bn.momentum, True, bn.moving_mean.value, bn.moving_var.value, like=y)
     _, out, tap = K.stem_pool_fwd(y, mean, rstd, bn.gamma.value, bn.beta.value)
-    out._p16f, out._p16b, out._p16_only = out.view(out.shape), None, True      # (a view, not `out` itself: no reference cycle through __dict__)
+    # `out` IS the f16 pair copy.  The alias must not lead back to `out`: `out` itself is a cycle through its own __dict__ (freed only by
+    # the cyclic GC: 105 MB per step at batch 16), and a VIEW is worse - its C-level `_base` edge is invisible to the GC, so the cycle
+    # out -> view -> out is never collected (round 5's first fix leaked 100 MB per eager step: profiles/r05_soak_2000steps_eager_leak.txt).
+    # detach() shares the storage and holds no reference to the tensor object.
+    out._p16f, out._p16b, out._p16_only = out.detach(), None, True
 
     def backward(g_out):
         sg, sb = GradSink(bn.gamma), GradSink(bn.beta)
