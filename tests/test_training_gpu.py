@@ -585,7 +585,8 @@ def test_gradient_policy_of_its_own_runs_the_backward_under_it(cuda, determinist
     assert runs[False][0] == runs[True][0] and not _same_weights(runs[False][1], runs[True][1])
 
 
-def test_eager_steps_do_not_leak_device_memory(cuda):
+@pytest.mark.parametrize("kind", ["detr", "boosted"])
+def test_eager_steps_do_not_leak_device_memory(cuda, kind):
     """Round 5 regression: a handle that referenced itself through a VIEW stored in its own __dict__ (the stem's pooled tensor aliasing
     its f16 pair copy) is a cycle the cyclic GC cannot see - a view's `_base` edge lives in C++ - and leaked one pooled tensor per eagerly
     enqueued step (100 MB at the bench's batch; the 2,000-step soak found it: profiles/r05_soak_2000steps_eager_leak.txt).  After a
@@ -596,7 +597,13 @@ def test_eager_steps_do_not_leak_device_memory(cuda):
     cfg, host = small_batch()
     batch = {"image": to_device(host["image"]), "category": to_device(host["category"], torch.int32), "attribute": to_device(host["attribute"], torch.int32),
              "bbox": to_device(host["bbox"]), "num_objects": to_device(host["num_objects"], torch.int32)}
-    m = small_model()
+    if kind == "boosted":
+        from boosted_detr_amd import parameters
+        from boosted_detr_amd.boosted_model import BoostedDETR
+        m = BoostedDETR(num_object_preds=10, image_size=(64, 64), num_encoder_blocks=1, num_encoder_heads=8, encoder_dim=256, num_decoder_blocks=2,
+                        num_decoder_heads=8, decoder_dim=256, num_panoptic_heads=1, panoptic_dim=32, vocab_dict=parameters.synthetic_vocab(10, 4), attribute_weight=1.0)
+    else:
+        m = small_model()
     m.compile(optimizer=SGD(learning_rate=1e-3, momentum=.9, nesterov=True, clipnorm=.1))
     held = []
     for _ in range(2):
