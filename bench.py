@@ -161,7 +161,7 @@ def step_hbm(ms_per_step):
 ENV_REFUSED = ("BDETR_SGEMM_DBG", "BDETR_GRAPH_UNSAFE")
 ENV_RECORDED = ("BDETR_STILE", "BDETR_TILE", "BDETR_P16", "BDETR_BN_FUSE", "BDETR_LAZY_SKIP", "BDETR_WGRAD_WANT", "BDETR_WGRAD_MINSTAGES",
                 "BDETR_GEMM_PRECISION", "BDETR_SIDE_STREAM", "BDETR_SIDE_PRIORITY", "BDETR_GRAPH", "BDETR_DP_OVERLAP", "BDETR_DP_FORCE", "BDETR_LIB",
-                "BDETR_CXXFLAGS", "BDETR_FORCE_DEVICE", "BDETR_DIST_BACKEND", "BDETR_CPU_THREADS", "BDETR_HCONV", "BDETR_ATTN_SPLIT", "BDETR_WGRAD_XF16", "BDETR_BF16_3X3", "BDETR_WGRAD_1X1_TILE", "BDETR_GRAPH_SEG", "BDETR_GRAPH_SIDE", "BDETR_DETERMINISTIC", "BDETR_ROWCHAIN", "BDETR_ZERO_MEMSET", "BDETR_DP_GRAPH", "BDETR_HWGRAD", "BDETR_BN_FUSE2", "BDETR_HCONV_TILE", "BDETR_STEM_FUSE", "BDETR_BN_WIDE_REDUCE", "BDETR_EVEN_PIXELS", "BDETR_WGRAD_WANT_64", "BDETR_COMPACT_S2", "BDETR_WGRAD_WANT_3X3", "BDETR_LAUNCH_PROBE")
+                "BDETR_CXXFLAGS", "BDETR_FORCE_DEVICE", "BDETR_DIST_BACKEND", "BDETR_CPU_THREADS", "BDETR_HCONV", "BDETR_ATTN_SPLIT", "BDETR_WGRAD_XF16", "BDETR_BF16_3X3", "BDETR_WGRAD_1X1_TILE", "BDETR_GRAPH_SEG", "BDETR_GRAPH_SIDE", "BDETR_DETERMINISTIC", "BDETR_ROWCHAIN", "BDETR_ZERO_MEMSET", "BDETR_DP_GRAPH", "BDETR_HWGRAD", "BDETR_BN_FUSE2", "BDETR_HCONV_TILE", "BDETR_STEM_FUSE", "BDETR_BN_WIDE_REDUCE", "BDETR_EVEN_PIXELS", "BDETR_WGRAD_WANT_64", "BDETR_COMPACT_S2", "BDETR_STEM_S2D", "BDETR_WGRAD_WANT_3X3", "BDETR_LAUNCH_PROBE")
 
 
 def env_overrides() -> dict:

@@ -139,7 +139,10 @@ SIGNATURES = {
     "bdetr_maxpool3x3s2_bwd": (I, [P, P, P, P, I, I, I, I, I, I, P]),
     "bdetr_stem_pool_bwd_chunks": (I, [L]),
     "bdetr_stem_pool_fwd": (I, [P, P, P, P, P, I, I, I, I, P, P, P, P, P]),
-    "bdetr_stem_pool_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, P, P, P, P, P]),
+    "bdetr_stem_pool_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, P, I, P, P, P, P]),
+    "bdetr_p16_s2d_pack_bf16": (I, [P, I, I, I, P, P]),
+    "bdetr_p16_stem_bwd_weight": (I, [P, P, P, I, I, I, I, P]),
+    "bdetr_p16_s2d_unpack_dw": (I, [P, P, I, P]),
     "bdetr_attention_head_dim": (I, []),
     "bdetr_attention_fwd": (I, [P, P, P, P, P, I, I, I, I, F, P]),
     "bdetr_attention_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, F, P]),

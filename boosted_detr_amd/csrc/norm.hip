@@ -477,7 +477,9 @@ struct StemBwdFn {   // a = g, b = g * xhat  (colreduce2_kernel functor; `r` is 
 __global__ __launch_bounds__(256) void stem_bwd_apply_kernel(const float* __restrict__ dpool, const unsigned* __restrict__ tap, const float* __restrict__ y,
                                                              const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, const float* __restrict__ dgamma, const float* __restrict__ dbeta,
-                                                             StemGeom s, float* __restrict__ dy, int64_t n4, float inv_rows) {
+                                                             StemGeom s, float* __restrict__ dy, int dy_p16, int64_t n4, float inv_rows) {
+    // dy_p16 (round 5): dy is written as the bf16 pair the stem's pre-split weight gradient reads (bdetr_p16_stem_bwd_weight) - the same
+    // 4 bytes per element, no fp32 copy (n4 and the stride are even: the two lanes of a pair share every trip, p16_store4)
     const int c4n = s.C / 4;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     auto one = [&](int64_t i, int c, const f32x4 m, const f32x4 rs, const f32x4 gm, const f32x4 bt, const f32x4 dg, const f32x4 db) {
@@ -487,7 +489,8 @@ __global__ __launch_bounds__(256) void stem_bwd_apply_kernel(const float* __rest
         f32x4 r;
 #pragma unroll
         for (int e = 0; e < 4; ++e) r[e] = bn_bwd_dx(g[e], yv[e], m[e], rs[e], gm[e], dg[e], db[e], inv_rows);      // bn_bwd_apply_kernel's expression
-        reinterpret_cast<f32x4*>(dy)[i] = r;
+        if (dy_p16) p16_store4<false>(dy, i, r[0], r[1], r[2], r[3]);
+        else reinterpret_cast<f32x4*>(dy)[i] = r;
     };
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (stride % c4n == 0) {                                   // (uniform; always for the stem's 64 channels: a thread keeps its channel group)
@@ -964,7 +967,7 @@ constexpr int STEM_BWD_CHUNKS = 2048;
 extern "C" int bdetr_stem_pool_bwd_chunks(int64_t rows) { return (int)cdiv64(rows, chunk_rows_for(rows, STEM_BWD_CHUNKS, 64)); }
 
 extern "C" int bdetr_stem_pool_bwd(const float* dpool, const uint8_t* tap, const float* y, const float* mean, const float* rstd, const float* gamma,
-                                   const float* beta, int N, int H, int W, int C, float* dy, float* dgamma, float* dbeta, float* ws, void* stream) {
+                                   const float* beta, int N, int H, int W, int C, float* dy, int dy_p16, float* dgamma, float* dbeta, float* ws, void* stream) {
     BDETR_CHECK_ARG(dpool && tap && y && mean && rstd && gamma && beta && dy && dgamma && dbeta && ws && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0,
                     "bdetr_stem_pool_bwd: bad arguments (C %% 8 == 0 required)");
     BDETR_CHECK_ARG((int64_t)N * H * W < (int64_t)1 << 31, "bdetr_stem_pool_bwd: more than 2^31 pixels");
@@ -981,7 +984,7 @@ extern "C" int bdetr_stem_pool_bwd(const float* dpool, const uint8_t* tap, const
     sum_partials2(pa, pb, nch, C, dbeta, dgamma, st);
     const int64_t n4 = rows * C / 4;
     hipLaunchKernelGGL(stem_bwd_apply_kernel, dim3(ew_grid(n4, 256, 2)), dim3(256), 0, st, dpool, reinterpret_cast<const unsigned*>(tap), y, mean, rstd, gamma, beta,
-                       dgamma, dbeta, s, dy, n4, 1.0f / (float)rows);
+                       dgamma, dbeta, s, dy, dy_p16, n4, 1.0f / (float)rows);
     return bdetr_launch_status("stem_pool_bwd");
 }
 

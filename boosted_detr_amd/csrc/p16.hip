@@ -109,3 +109,45 @@ extern "C" int bdetr_p16_pack_conv_weights(const float* w, int K, int R, int S, 
     if (wt_bf16) hipLaunchKernelGGL(p16_pack_wt_kernel, dim3(ew_grid(n / 8, 256, 1)), dim3(256), 0, st, w, K, R, S, C, wt_bf16);
     return bdetr_launch_status("p16_pack_conv_weights");
 }
+
+// ---- the stem's weight gradient on the pre-split path (round 5) -------------------------------------------------------------------
+// keras ResNet50 conv1_conv (7x7 / stride 2 on the ZeroPadding2D(3) image; reference backbone.py:37-38) reads a 4-channel image - no
+// P16 layout for that (groups of 8 channels).  Space-to-depth turns it into a size-preserving stride-1 convolution: x2[n][i][j][(a, b, c)] =
+// x[n][2 i + a][2 j + b][c] (16 channels on the H/2 x W/2 grid), tap (r, s) of the 7x7 kernel = tap (r', s') of a 4x4 kernel over x2 with
+// r = 2 r' + a - 1 (r = -1: no such tap), low-side padding 2.  The weight gradient then is sgemm.hip's XX kernel over x2's bf16 pairs
+// ([K][4][4][16] fp32) and bdetr_p16_s2d_unpack_dw folds it back into the [K][7][7][4] layout.
+namespace {
+__global__ __launch_bounds__(256) void s2d_pack_bf16_kernel(const float* __restrict__ x, int N, int H, int W, void* __restrict__ out) {
+    const int H2 = H >> 1, W2 = W >> 1;
+    const int64_t n = (int64_t)N * H2 * W2 * 2;                  // one 8-element group (a; b = 0, 1; c = 0..3) per thread
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        const int a = (int)(t & 1); int64_t p = t >> 1;
+        const int j = (int)(p % W2); p /= W2; const int i = (int)(p % H2); const int b_ = (int)(p / H2);
+        const f32x4* row = reinterpret_cast<const f32x4*>(x) + ((int64_t)b_ * H + 2 * i + a) * W + 2 * j;
+        const f32x4 p0 = row[0], p1 = row[1];
+        const float v[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+        p16_store8<false>(reinterpret_cast<char*>(out) + t * 32, v);
+    }
+}
+__global__ __launch_bounds__(256) void s2d_unpack_dw_kernel(const float* __restrict__ dw2, float* __restrict__ dw, int K) {
+    const int n = K * 7 * 7 * 4;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+        const int c = t & 3; int q = t >> 2;
+        const int s = q % 7; q /= 7; const int r = q % 7; const int k = q / 7;
+        const int rp = (r + 1) >> 1, a = (r + 1) & 1, sp = (s + 1) >> 1, b = (s + 1) & 1;
+        dw[t] = dw2[k * 256 + (rp * 4 + sp) * 16 + (a * 2 + b) * 4 + c];
+    }
+}
+}  // namespace
+
+extern "C" int bdetr_p16_s2d_pack_bf16(const float* x, int N, int H, int W, void* out_bf16, void* stream) {
+    BDETR_CHECK_ARG(x && out_bf16 && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "bdetr_p16_s2d_pack_bf16: a [N,H,W,4] image with even H and W");
+    const int64_t n = (int64_t)N * (H / 2) * (W / 2) * 2;
+    hipLaunchKernelGGL(s2d_pack_bf16_kernel, dim3(ew_grid(n, 256, 2)), dim3(256), 0, (hipStream_t)stream, x, N, H, W, out_bf16);
+    return bdetr_launch_status("p16_s2d_pack_bf16");
+}
+extern "C" int bdetr_p16_s2d_unpack_dw(const float* dw2, float* dw, int K, void* stream) {
+    BDETR_CHECK_ARG(dw2 && dw && K > 0, "bdetr_p16_s2d_unpack_dw: bad arguments");
+    hipLaunchKernelGGL(s2d_unpack_dw_kernel, dim3((K * 196 + 255) / 256), dim3(256), 0, (hipStream_t)stream, dw2, dw, K);
+    return bdetr_launch_status("p16_s2d_unpack_dw");
+}

@@ -1202,3 +1202,35 @@ extern "C" int bdetr_p16_conv2d_bwd_weight_xf16(const void* x_f16, const void* d
                                                 const bdetr_conv_desc* d, int splitk, void* stream) {
     return p16_bwd_weight(x_f16, 1, dy_bf16, dw, d, splitk, stream);
 }
+
+// The stem's weight gradient over the space-to-depth image (p16.hip: bdetr_p16_s2d_pack_bf16): x2 P16-bf16 [N,H2,W2,16], dy P16-bf16
+// [N,H2,W2,K]; dw2 fp32 [K][4][4][16], holding zeros on entry (the split-K slices add with float atomics).  The 4x4 kernel sits at
+// low-side padding 2 over a size-preserving map (OH = H2: the high side has padding 1) - an asymmetric geometry bdetr_conv_desc
+// cannot state, hence the entry point of its own.  Replaces the kernel gradient of keras ResNet50 conv1_conv (reference backbone.py:37-38 +
+// autodiff), which igemm.hip's in-kernel-split kernel computed in 355-470 us as the LAST kernel of the backward pass.
+extern "C" int bdetr_p16_stem_bwd_weight(const void* x2_bf16, const void* dy_bf16, float* dw2, int N, int H2, int W2, int K, void* stream) {
+    BDETR_CHECK_ARG(x2_bf16 && dy_bf16 && dw2 && N > 0 && H2 > 0 && W2 > 0 && K > 0 && K % 64 == 0 && aligned16(x2_bf16) && aligned16(dy_bf16),
+                    "bdetr_p16_stem_bwd_weight: bad arguments (K %% 64 == 0)");
+    const int64_t M64 = (int64_t)N * H2 * W2;
+    BDETR_CHECK_ARG(M64 < (1LL << 31) && span_ok(M64 * 16) && span_ok(M64 * K), "bdetr_p16_stem_bwd_weight: tensors of 4 GB or more");
+    const int M = (int)M64, Kd = 4 * 4 * 16;
+    GemmParams g; init_params(g);
+    // (the transposed product - [256][K] on 128 x 64 tiles, dy staged by two row tiles instead of four column tiles - measured slower: 309 against 279 us)
+    g.I = K; g.J = Kd; g.R = M; g.c = dw2; g.ldc = Kd;
+    const int64_t tiles = cdiv64(K, 64) * cdiv64(Kd, 64);
+    int64_t sk = (16LL * num_cus()) / tiles;                          // few output tiles over a very long pixel range: 16 workgroups per CU (igemm.hip's few-tiles rule)
+    const int64_t maxsk = cdiv64(M, 8LL * BK);
+    if (sk > maxsk) sk = maxsk;
+    if (sk < 1) sk = 1;
+    if (sk > 1024) sk = 1024;
+    int zdim = 1;
+    if (sk > 1) {
+        g.r_chunk = (int)(cdiv64(cdiv64(M, sk), BK) * BK);
+        zdim = (int)cdiv64(M, g.r_chunk);
+        g.splitk = zdim > 1 ? zdim : 2;
+        g.mode = ST_ATOMIC;
+    }
+    PDense a{dy_bf16, (unsigned)K, M, K};
+    PPatch b = make_patch(x2_bf16, N, H2, W2, 16, H2, W2, 4, 4, 1, 2, M, Kd);
+    return launch_any<XXDense, XXPatch, true, false>(a, b, g, zdim, (hipStream_t)stream, 3000, T_64x64);
+}

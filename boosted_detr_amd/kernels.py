@@ -740,8 +740,9 @@ def stem_pool_fwd(y, mean, rstd, gamma, beta, want_fp32=False):
     return o32, of, tap
 
 
-def stem_pool_bwd(dpool, tap, y, mean, rstd, gamma, beta, dgamma=None, dbeta=None):
-    """The backward of stem_pool_fwd + BatchNorm (batch statistics): (dy [N,H,W,C], dgamma, dbeta)."""
+def stem_pool_bwd(dpool, tap, y, mean, rstd, gamma, beta, dgamma=None, dbeta=None, dy_p16=False):
+    """The backward of stem_pool_fwd + BatchNorm (batch statistics): (dy [N,H,W,C], dgamma, dbeta).  dy_p16: dy as the bf16 pair
+    of the P16 layout (what stem_bwd_weight_s2d reads) instead of fp32 - same shape, never read as floats."""
     _chk(dpool, y, mean, rstd, gamma, beta, dgamma, dbeta)
     assert tap.is_cuda and tap.is_contiguous() and tap.dtype == torch.uint8 and tuple(tap.shape) == tuple(dpool.shape)
     L = _lib.lib()
@@ -750,9 +751,26 @@ def stem_pool_bwd(dpool, tap, y, mean, rstd, gamma, beta, dgamma=None, dbeta=Non
     dgamma = empty(Cc, like=y) if dgamma is None else dgamma
     dbeta = empty(Cc, like=y) if dbeta is None else dbeta
     ws = empty(2 * Cc * L.bdetr_stem_pool_bwd_chunks(N * H * W), like=y)
-    check(L.bdetr_stem_pool_bwd(_p(dpool), _p(tap), _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), N, H, W, Cc, _p(dy), _p(dgamma), _p(dbeta),
+    check(L.bdetr_stem_pool_bwd(_p(dpool), _p(tap), _p(y), _p(mean), _p(rstd), _p(gamma), _p(beta), N, H, W, Cc, _p(dy), int(dy_p16), _p(dgamma), _p(dbeta),
                                 _p(ws), _stream()), "stem_pool_bwd")
     return dy, dgamma, dbeta
+
+
+def stem_bwd_weight_s2d(x4, dy_bf16, dw):
+    """dw [K,7,7,4] <- the weight gradient of the ResNet stem (7x7 / stride 2 / pad 3 over the 4-channel image x4 [N,H,W,4], H and W even)
+    from dy's bf16 pair [N,H/2,W/2,K]: space-to-depth image pack, the pre-split XX kernel on a 4x4 / 16-channel view, unpack (include/bdetr.h)."""
+    _chk(x4, dy_bf16, dw)
+    L = _lib.lib()
+    N, H, W, Cc = x4.shape
+    Kout = dw.shape[0]
+    assert Cc == 4 and H % 2 == 0 and W % 2 == 0 and tuple(dw.shape) == (Kout, 7, 7, 4) and tuple(dy_bf16.shape) == (N, H // 2, W // 2, Kout)
+    x2 = empty(N, H // 2, W // 2, 16, like=x4)
+    check(L.bdetr_p16_s2d_pack_bf16(_p(x4), N, H, W, _p(x2), _stream()), "p16_s2d_pack_bf16")
+    dw2 = empty(Kout, 4, 4, 16, like=x4)
+    check(L.bdetr_zero(_p(dw2), dw2.numel(), _stream()), "zero")
+    check(L.bdetr_p16_stem_bwd_weight(_p(x2), _p(dy_bf16), _p(dw2), N, H // 2, W // 2, Kout, _stream()), "p16_stem_bwd_weight")
+    check(L.bdetr_p16_s2d_unpack_dw(_p(dw2), _p(dw), Kout, _stream()), "p16_s2d_unpack_dw")
+    return dw
 
 
 def attention_fwd(q, k, v, heads, scale):

@@ -527,6 +527,7 @@ def maxpool(x: torch.Tensor) -> torch.Tensor:
 
 
 STEM_FUSE = os.environ.get("BDETR_STEM_FUSE", "1") != "0"
+STEM_S2D = os.environ.get("BDETR_STEM_S2D", "1") != "0"            # the stem's weight gradient on the pre-split path (conv_bn_relu_maxpool backward)
 
 
 def conv_bn_relu_maxpool(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int, pad: int, training: bool,
@@ -554,14 +555,24 @@ def conv_bn_relu_maxpool(x: torch.Tensor, w: Variable, b: Variable, bn: BNState,
 
     def backward(g_out):
         sg, sb = GradSink(bn.gamma), GradSink(bn.beta)
-        dy, _, _ = K.stem_pool_bwd(materialise(g_out).contiguous(), tap, y, mean, rstd, bn.gamma.value, bn.beta.value, dgamma=sg.buf, dbeta=sb.buf)
+        # The weight gradient of the 7x7 / stride-2 / pad-3 stem over a 4-channel image with even sides runs on the pre-split XX kernel
+        # through a space-to-depth view (kernels.stem_bwd_weight_s2d, round 5): it is the LAST kernel of the backward pass, alone on the chip
+        # with the optimizer waiting for it.  dy is then written as its bf16 pair.  Gradient products under 'split' are bf16 pairs on
+        # both paths; any other backward policy, deterministic mode and other geometries keep igemm.hip's kernel.
+        s2d = (STEM_S2D and w.needs_grad and (R, S, stride, pad, Cin) == (7, 7, 2, 3, 4) and H % 2 == 0 and W % 2 == 0 and Kout % 64 == 0
+               and K.get_gemm_precision() in ("split", "mixed") and not K.deterministic())
+        dy, _, _ = K.stem_pool_bwd(materialise(g_out).contiguous(), tap, y, mean, rstd, bn.gamma.value, bn.beta.value, dgamma=sg.buf, dbeta=sb.buf,
+                                   dy_p16=s2d)
         sg.commit()
         sb.commit()
         if w.needs_grad or b.needs_grad:
             def param_grads(dy=dy):
                 if w.needs_grad:
                     s = GradSink(w)
-                    K.conv2d_bwd_weight(x32, dy, g, dw=s.buf, prezeroed=s.mode == "direct")
+                    if s2d:
+                        K.stem_bwd_weight_s2d(x32, dy, s.buf)
+                    else:
+                        K.conv2d_bwd_weight(x32, dy, g, dw=s.buf, prezeroed=s.mode == "direct")
                     s.commit()
                 if b.needs_grad:
                     s = GradSink(b)             # exactly zero in front of a batch-statistics BatchNorm (see conv_bn)

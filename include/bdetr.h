@@ -382,7 +382,17 @@ int bdetr_stem_pool_bwd_chunks(int64_t rows);
 int bdetr_stem_pool_fwd(const float* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
                         int N, int H, int W, int C, float* out32, void* out_f16, uint8_t* tap, int* overflow_flag, void* stream);
 int bdetr_stem_pool_bwd(const float* dpool, const uint8_t* tap, const float* y, const float* mean, const float* rstd, const float* gamma,
-                        const float* beta, int N, int H, int W, int C, float* dy, float* dgamma, float* dbeta, float* ws, void* stream);
+                        const float* beta, int N, int H, int W, int C, float* dy, int dy_p16 /* ABI 7: write dy as the P16 bf16 pair
+                        (the operand of bdetr_p16_stem_bwd_weight) instead of fp32 */, float* dgamma, float* dbeta, float* ws, void* stream);
+/* The stem's weight gradient on pre-split operands (ABI 7).  keras ResNet50 conv1_conv - 7x7 / stride 2 on the ZeroPadding2D(3) image,
+ * reference backbone.py:37-38 - reads a 4-channel image, which the P16 layout (groups of 8 channels) cannot hold; space-to-depth makes it
+ * a size-preserving stride-1 4x4 convolution over x2[n][i][j][(a,b,c)] = x[n][2i+a][2j+b][c] (16 channels, low-side padding 2), tap (r,s) =
+ * (2r'+a-1, 2s'+b-1).  bdetr_p16_s2d_pack_bf16: x fp32 [N,H,W,4] (H, W even) -> x2 P16-bf16 [N,H/2,W/2,16].  bdetr_p16_stem_bwd_weight:
+ * dw2 fp32 [K][4][4][16] += sum over pixels of dy x patches(x2) (dw2 must hold zeros: split-K float atomics; K % 64 == 0; dy P16-bf16
+ * [N,H/2,W/2,K]).  bdetr_p16_s2d_unpack_dw: dw [K][7][7][4] <- dw2 (the r = -1 / s = -1 taps of the 4x4 form do not exist and are dropped). */
+int bdetr_p16_s2d_pack_bf16(const float* x, int N, int H, int W, void* out_bf16, void* stream);
+int bdetr_p16_stem_bwd_weight(const void* x2_bf16, const void* dy_bf16, float* dw2, int N, int H2, int W2, int K, void* stream);
+int bdetr_p16_s2d_unpack_dw(const float* dw2, float* dw, int K, void* stream);
 
 /* ------------------------------------------------------------------------
  * K7  attention softmax (transformers.py:88-94): p = softmax(scale*s) row-wise, in place ok.

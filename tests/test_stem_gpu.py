@@ -113,3 +113,30 @@ def test_stem_op_fused_equals_unfused(cuda, B, H):
     for n in a[1]:
         close(b[1][n], a[1][n], rtol=1e-6, atol=1e-6 * max(float(a[1][n].abs().max()), 1e-3))
     assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+
+
+@pytest.mark.parametrize("N,H,W", [(2, 32, 48), (1, 64, 64), (3, 18, 22), (4, 224, 224)])
+def test_stem_weight_gradient_on_the_space_to_depth_path(cuda, N, H, W):
+    """Round 5: the 7x7 / stride-2 / pad-3 stem's weight gradient through a space-to-depth view of the 4-channel image (x2 [N,H/2,W/2,16], a
+    4x4 size-preserving convolution with low-side padding 2) on the pre-split XX kernel: against the fp64 gradient of the same convolution
+    (bf16-pair products: 2e-5 of the tensor's scale, the igemm kernel's own bound) and against igemm.hip's kernel under the same policy."""
+    from boosted_detr_amd import kernels as k
+    K_ = 64
+    x = rnd(N, H, W, 4, seed=1, scale=40.0)
+    x[..., 3] = 0                                                       # the padding channel image_prep adds
+    dy = rnd(N, H // 2, W // 2, K_, seed=2)
+    xt = x.double().permute(0, 3, 1, 2).requires_grad_(False)
+    wt = torch.zeros(K_, 4, 7, 7, dtype=torch.float64, requires_grad=True)
+    out = F.conv2d(xt, wt, stride=2, padding=3)
+    assert tuple(out.shape) == (N, K_, H // 2, W // 2)
+    out.backward(dy.double().permute(0, 3, 1, 2))
+    want = wt.grad.permute(0, 2, 3, 1).contiguous()                     # [K,7,7,4]
+    with k.gemm_precision("split"):
+        _, dyb = k.p16_pack(dev(dy), want_f16=False)
+        got = k.stem_bwd_weight_s2d(dev(x), dyb, torch.full((K_, 7, 7, 4), 7.0, device="cuda"))       # (every element is overwritten)
+        g = k.ConvGeom(N, H, W, 4, K_, 7, 7, 2, 3)
+        old = k.conv2d_bwd_weight(dev(x), dev(dy), g)
+    scale = float(want.abs().max())
+    assert float((got.double().cpu() - want).abs().max()) <= 3e-5 * scale, float((got.double().cpu() - want).abs().max()) / scale
+    assert float((old.double().cpu() - want).abs().max()) <= 3e-5 * scale
+    assert float(got[..., 3].abs().max()) == 0.0
