@@ -983,7 +983,7 @@ extern "C" int bdetr_conv2d_bwd_weight_splitk(const bdetr_conv_desc* d) {
     // A handful of output tiles over a very long pixel range - the stem's 64 x 196 gradient over 1.6 M pixels, the LAST kernel of the
     // backward pass, alone on the chip with the optimizer waiting for it: 16 workgroups per CU instead of 3 (tools/stem_wgrad_probe.py,
     // round 5: split 192 -> 467 us, 1024 -> 355 us)
-    const bool few_tiles = tiles <= 8;
+    const bool few_tiles = tiles <= 8 && M >= (1 << 20);      // (the pixel-count bound keeps the stage-2 layers of the igemm backward policies - bf16x6, fp32: 0.4 M pixels, 1-4 tiles - on their 3 workgroups per CU: 1,024 slices of 64-KB atomics each cost value_fp32_grade 22 %)
     if (few_tiles) want = 16LL * num_cus();
     int64_t sk = cdiv64(want, tiles);
     int64_t maxsk = cdiv64(M, 4 * BK);      // keep >= 4 stages per split
