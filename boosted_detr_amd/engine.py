@@ -188,7 +188,8 @@ def materialise(g):
         # products wrote (ops.conv_bn).  Its two regular consumers read it through the pixel map; anybody else gets the dense
         # zero-filled tensor, built here (a torch strided copy: the fallback, not the step's path) - a NEW tensor: callers re-bind.
         N, H, W = c
-        d = torch.zeros(N, H, W, g.shape[-1], dtype=g.dtype, device=g.device)
+        d = torch.empty(N, H, W, g.shape[-1], dtype=g.dtype, device=g.device)
+        K.zero_(d)                                   # (a kernel, not torch.zeros: a hipMemset node must not enter a captured step - SegmentedCapture.census)
         d[:, ::2, ::2] = g.view(N, H // 2, W // 2, g.shape[-1])
         d._bdetr_owned = True
         d._even_pixels = (N, H, W)

@@ -614,3 +614,39 @@ def test_eager_steps_do_not_leak_device_memory(cuda, kind):
         gc.collect()
         held.append(torch.cuda.memory_allocated())
     assert held[1] <= held[0] + (1 << 17), f"device memory grew by {(held[1] - held[0]) / 2 ** 20:.1f} MiB over six eager steps"
+
+
+def test_compact_stride2_gradients_and_their_fallbacks_give_the_same_step(cuda, deterministic):
+    """The gradient of a stage's last unit as a compact even-pixel tensor (ops.COMPACT_S2, round 5) against the zero-filled scatter form
+    it replaces, and against the fallback in which its consumer cannot take it compact and engine.materialise expands it
+    (ops.LAZY_SKIP off): every parameter gradient of a training step agrees (deterministic mode: the only difference is where zeros
+    are added, so the compact / scatter pair is bit-identical)."""
+    from boosted_detr_amd import ops
+    from boosted_detr_amd.engine import to_device
+    from boosted_detr_amd.training import SGD
+    from oracle import detr_oracle as O
+    cfg, host = small_batch()
+    params = O.make_params(cfg, seed=1)
+    batch = {"image": to_device(host["image"]), "category": to_device(host["category"], torch.int32), "attribute": to_device(host["attribute"], torch.int32),
+             "bbox": to_device(host["bbox"]), "num_objects": to_device(host["num_objects"], torch.int32)}
+    keep = (ops.COMPACT_S2, ops.LAZY_SKIP)
+    grads = {}
+    try:
+        for name, (compact, lazy) in {"compact": (True, True), "scatter": (False, True), "expanded": (True, False)}.items():
+            ops.COMPACT_S2, ops.LAZY_SKIP = compact, lazy
+            m = small_model()
+            m.compile(optimizer=SGD(learning_rate=1e-3, momentum=.9, nesterov=True, clipnorm=.1))
+            m.forward_backward(batch)
+            m.set_weights_dict(params)
+            m.forward_backward(batch)
+            torch.cuda.synchronize()
+            grads[name] = {v.name: v.grad.detach().clone() for v in m.trainable_variables if v.grad is not None}
+    finally:
+        ops.COMPACT_S2, ops.LAZY_SKIP = keep
+    assert len(grads["compact"]) > 100
+    bad = [k for k, g in grads["compact"].items() if not torch.equal(g, grads["scatter"][k])]
+    assert not bad, bad[:5]
+    for k, g in grads["compact"].items():
+        e = grads["expanded"][k]
+        scale = float(g.abs().max()) + 1e-30
+        assert float((g - e).abs().max()) <= 1e-4 * scale, (k, float((g - e).abs().max()) / scale)      # (another order of fp32 adds and bf16-pair roundings along the skip path)

@@ -7,10 +7,10 @@ import boosted_detr_amd          # (before the first CUDA call: sets the hipGrap
 import torch
 import bench
 class A: pass
-a = A(); a.queries = 100; a.image = 640; a.layers = 6; a.batch = 16; a.model = 'detr'; a.fashionpedia = False; a.image_w = 0; a.learners = 3; a.backbone = 'ResNet'; a.panoptic = False
+a = A(); a.queries = 100; a.image = 640; a.layers = 6; a.batch = 16; a.model = (sys.argv[4] if len(sys.argv) > 4 else 'detr'); a.fashionpedia = a.model == 'boosted'; a.image_w = 0; a.learners = 3; a.backbone = 'ResNet'; a.panoptic = False
 from boosted_detr_amd.engine import to_device
 m = bench.build_model(a)
-host = bench.make_batch(16, 640, 640, 100, 82, 1234)
+host = bench.make_batch(16, 640, 640, 100, 48 if a.fashionpedia else 82, 1234, **({'A': 296} if a.fashionpedia else {}))
 batch = {"image": to_device(host["image"]), "category": host["category"], "attribute": host["attribute"], "bbox": to_device(host["bbox"]), "num_objects": to_device(host["num_objects"], torch.int32)}
 GRAPH = len(sys.argv) > 3 and sys.argv[3] == "graph"
 if GRAPH:
