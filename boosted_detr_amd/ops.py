@@ -457,10 +457,13 @@ def conv_bn(x: torch.Tensor, w: Variable, b: Variable, bn: BNState, stride: int,
         if x_needs_grad:
             if acc is not None and acc[0] is not None:
                 # residual merge fused into the GEMM epilogue: dx += conv_transpose(dy) (no separate add pass)
-                dx = K.conv2d_bwd_data(dy4, w.value, g, dx=materialise(acc[0]).view(N, H, W, Cin), accumulate=True)
-                if hasattr(acc[0], "_even_pixels"):
-                    del acc[0]._even_pixels
-                dx = acc[0]
+                base = materialise(acc[0])                  # (a compact even-pixel gradient comes back as a NEW dense tensor)
+                K.conv2d_bwd_data(dy4, w.value, g, dx=base.view(N, H, W, Cin), accumulate=True)
+                if hasattr(base, "_even_pixels"):
+                    del base._even_pixels
+                dx = base
+                if base is not acc[0]:
+                    dx._replaces_acc = True                 # (engine.Tape re-binds the accumulated gradient to it)
             else:
                 dx = _own(K.conv2d_bwd_data(dy4, w.value, g))
         dr = _own(dres.view(residual.shape)) if want_res else None

@@ -418,6 +418,28 @@ def test_stride2_backward_data_gradients_carry_the_even_pixel_tag(cuda):
     off = sparse.clone()
     off[:, ::2, ::2] = 0
     assert float(off.abs().max()) == 0.0 and float(sparse.abs().max()) > 0
+    # a FROZEN consumer (moving statistics: the fp32 path, not the pre-split one) next to a trainable stride-2 one, in either order: the
+    # compact tensor meets a convolution that cannot take it compact, and the merged gradient equals the scatter form's
+    fz = _ConvBN("t/", "c9", "b9", C, 128, 1, 2, 0, seed=9)
+    fz.trainable = False
+    try:
+        with k.gemm_precision("split"):
+            for compact in (True, False):
+                ops.COMPACT_S2 = compact
+                for layers in ((a, fz), (fz, a)):
+                    x = x32.clone()
+                    xf, _ = k.p16_pack(x, want_f16=True, want_bf16=False)
+                    x._p16f, x._p16b = xf, None
+                    tape = Tape()
+                    with recording(tape):
+                        outs = [l([x], training=True, relu=True, want_fp32=True) for l in layers]
+                    grads = tape.backward({id(o): dev(rnd(*o.shape, seed=17 + i)) for i, o in enumerate(outs)})
+                    join_side_stream()
+                    seen[("fz", compact, layers)] = materialise(grads[id(x)])
+    finally:
+        ops.COMPACT_S2 = keep
+    for layers in ((a, fz), (fz, a)):
+        close(seen[("fz", True, layers)], seen[("fz", False, layers)], rtol=1e-6)
 
 
 @pytest.mark.parametrize("N,H,W,C,K", [(2, 20, 20, 64, 256), (3, 8, 12, 256, 64), (16, 40, 40, 1024, 256)])
