@@ -177,6 +177,7 @@ class DataParallel:
     temporary gradients) goes out in ``finish``."""
 
     BUCKET_ELEMS = 8 * 1024 * 1024      # 32 MB fp32 buckets
+    TAIL_ELEMS = int(os.environ.get("BDETR_DP_TAIL_ELEMS", str(1024 * 1024)))      # ... except the last one to complete (prepare): 4 MB
 
     def __init__(self):
         import torch.distributed as dist
@@ -219,6 +220,13 @@ class DataParallel:
             lo = max(0, hi - self.BUCKET_ELEMS)
             self._bounds.append((lo, hi))
             hi = lo
+        # The bucket at the START of the buffer holds the first layers' gradients - the last ones the backward pass completes (the stem's
+        # weight gradient is its final kernel) - so its all-reduce cannot overlap anything: keep it SMALL.  Without this cut it is whatever
+        # the 32-MB grid leaves (28 MB at config 2: ~0.3 ms of exposed ring time per step at N = 8); with it the exposed collective is 4 MB
+        # and the rest of that bucket goes out ~5 ms earlier, when the backward pass reaches stage 3.  (Round 5; never measured at N > 1.)
+        lo, hi = self._bounds[-1]
+        if lo == 0 and hi > 2 * self.TAIL_ELEMS:
+            self._bounds[-1:] = [(self.TAIL_ELEMS, hi), (0, self.TAIL_ELEMS)]
         base = flat.data_ptr()
         self._var_bucket, self._bucket_size = {}, [0] * len(self._bounds)
         for v in optimizer.vars:

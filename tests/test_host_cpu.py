@@ -292,3 +292,16 @@ def test_data_parallel_cuda_branch_with_fake_streams(monkeypatch):
     flag = torch.zeros(1)
     dp.any_(flag)
     assert log[-1] == ("all_reduce", 1, "main")
+    # bucket table at the bench's size (31.0 M gradients, 32-MB buckets): the bucket that completes LAST - the first layers', at the start
+    # of the buffer - is cut to TAIL_ELEMS so that the all-reduce nothing can overlap is small (round 5)
+    big = FlatOnDevice(31_006_681)
+    vb = []
+    for i, (o, sz) in enumerate(((0, 9408), (500_000, 147_456), (1_048_000, 4_000), (20_000_000, 2_359_296))):
+        v = V(); v.name = f"b{i}"; v.grad_buf = big[o: o + sz]; v.grad = v.grad_buf; v._grad_flat = big
+        vb.append(v)
+    dp3 = training.DataParallel()
+    dp3.prepare(types.SimpleNamespace(flat_grad=big, vars=vb))
+    n, B, T = 31_006_681, dp3.BUCKET_ELEMS, dp3.TAIL_ELEMS
+    assert dp3._bounds[0] == (n - B, n) and dp3._bounds[-2:] == [(T, n - 3 * B), (0, T)] and len(dp3._bounds) == 5, dp3._bounds
+    assert all(a[0] == b[1] for a, b in zip(dp3._bounds[:-1], dp3._bounds[1:]))            # contiguous cover, high to low
+    assert dp3._var_bucket[id(vb[0])] == (4, 4) and dp3._var_bucket[id(vb[2])] == (4, 3) and dp3._var_bucket[id(vb[3])][0] == 1      # vb[2] straddles the cut: counted in both
