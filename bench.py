@@ -186,7 +186,7 @@ def step_hbm(ms_per_step):
 ENV_REFUSED = ("BDETR_SGEMM_DBG", "BDETR_GRAPH_UNSAFE")
 ENV_RECORDED = ("BDETR_STILE", "BDETR_TILE", "BDETR_P16", "BDETR_BN_FUSE", "BDETR_LAZY_SKIP", "BDETR_WGRAD_WANT", "BDETR_WGRAD_MINSTAGES",
                 "BDETR_GEMM_PRECISION", "BDETR_SIDE_STREAM", "BDETR_SIDE_PRIORITY", "BDETR_GRAPH", "BDETR_DP_OVERLAP", "BDETR_DP_FORCE", "BDETR_LIB",
-                "BDETR_CXXFLAGS", "BDETR_FORCE_DEVICE", "BDETR_DIST_BACKEND", "BDETR_CPU_THREADS", "BDETR_HCONV", "BDETR_ATTN_SPLIT", "BDETR_WGRAD_XF16", "BDETR_BF16_3X3", "BDETR_WGRAD_1X1_TILE", "BDETR_GRAPH_SEG", "BDETR_GRAPH_SIDE", "BDETR_DETERMINISTIC", "BDETR_ROWCHAIN", "BDETR_ZERO_MEMSET", "BDETR_DP_GRAPH", "BDETR_HWGRAD", "BDETR_BN_FUSE2", "BDETR_HCONV_TILE", "BDETR_STEM_FUSE", "BDETR_BN_WIDE_REDUCE", "BDETR_EVEN_PIXELS", "BDETR_WGRAD_WANT_64", "BDETR_COMPACT_S2", "BDETR_STEM_S2D", "BDETR_WGRAD_WANT_3X3", "BDETR_LAUNCH_PROBE")
+                "BDETR_CXXFLAGS", "BDETR_FORCE_DEVICE", "BDETR_DIST_BACKEND", "BDETR_CPU_THREADS", "BDETR_HCONV", "BDETR_ATTN_SPLIT", "BDETR_WGRAD_XF16", "BDETR_BF16_3X3", "BDETR_WGRAD_1X1_TILE", "BDETR_GRAPH_SEG", "BDETR_GRAPH_SIDE", "BDETR_DETERMINISTIC", "BDETR_ROWCHAIN", "BDETR_ZERO_MEMSET", "BDETR_DP_GRAPH", "BDETR_HWGRAD", "BDETR_BN_FUSE2", "BDETR_HCONV_TILE", "BDETR_STEM_FUSE", "BDETR_BN_WIDE_REDUCE", "BDETR_EVEN_PIXELS", "BDETR_WGRAD_WANT_64", "BDETR_COMPACT_S2", "BDETR_STEM_S2D", "BDETR_WGRAD_WANT_3X3", "BDETR_LAUNCH_PROBE", "BDETR_SIDE_CANDIDATES", "BDETR_SIDE_QUEUE_SKIP", "BDETR_SIDE_TUNE", "BDETR_DP_TAIL_ELEMS")
 
 
 def env_overrides() -> dict:
@@ -407,6 +407,16 @@ def main():
         if args.panoptic:
             masks[0] = model.panoptic_masks()
 
+    if distributed:
+        # set-up, like the build: a data-parallel model settles the placement of its side stream by timing its first eager steps on each
+        # candidate (training.Model._side_tune_begin: a schedule of fixed length, the same on every rank)
+        n_tune = 0
+        while model.side_tuning_pending() and n_tune < 24:
+            run_step(batch)
+            n_tune += 1
+        torch.cuda.synchronize()
+        from boosted_detr_amd import engine as _engine
+        note(f"side-stream placement after {n_tune} set-up steps: {_engine.side_stream_placement()}")
     if model.use_graph:
         # build-by-first-call, allocator warm-up and the capture itself (third step on a signature) are set-up, like the build:
         # they happen before the W warm-up steps, so that warm-up and timed steps are all replays whatever W is
@@ -711,7 +721,11 @@ def main():
                        "runtime_switches": {"DEBUG_CLR_GRAPH_PACKET_CAPTURE": os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE"),
                                             "packet_capture_off_in_force": boosted_detr_amd.packet_capture_off(),
                                             "zero_fill": "hipMemset nodes" if os.environ.get("BDETR_ZERO_MEMSET") == "1" else "library kernel (no memset nodes in the captured step)"}, "gflop_per_image_algorithmic": gflop_img,
-                       "configs3": b32, "configs2": c2, "env_overrides": overrides, "distributed": dist_info},
+                       "configs3": b32, "configs2": c2, "env_overrides": overrides, "distributed": dist_info,
+                       # which of its candidate hardware queues the weight-gradient stream runs on and what the choice was made from
+                       # (engine.side_stream: tick_ms = the critical path's small kernels under each candidate's load; step_ms = a
+                       # data-parallel model's timed steps on the good ones)
+                       "side_stream_placement": __import__("boosted_detr_amd.engine", fromlist=["x"]).side_stream_placement()},
             "tflops_algorithmic": round(value * gflop_img / 1e3, 2) if gflop_img else None,
             # whole step against the two roofs (the judge's cross-checks): algorithmic FLOPs / step time / 3-product MFMA roof, and the step's
             # measured HBM traffic (committed PMC passes) / this run's step time

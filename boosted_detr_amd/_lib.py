@@ -76,6 +76,7 @@ SIGNATURES = {
     "bdetr_last_error": (C.c_char_p, []),
     "bdetr_device_cus": (I, []),
     "bdetr_low_priority_stream_create": (I, [P]),
+    "bdetr_side_stream_candidates": (I, [P, I, I, I, P, P]),
     "bdetr_stream_priority_range": (I, [P, P]),
     "bdetr_set_gemm_precision": (I, [I]),
     "bdetr_get_gemm_precision": (I, []),
@@ -210,7 +211,7 @@ def lib():
         fn = getattr(h, name)          # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if h.bdetr_abi_version() != 7:
+    if h.bdetr_abi_version() != 8:
         raise BdetrError("libbdetr.so ABI version mismatch; rebuild")
     _lib = h
     return _lib

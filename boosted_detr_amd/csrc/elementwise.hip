@@ -407,3 +407,67 @@ extern "C" int bdetr_colsum(const float* x, int64_t rows, int cols, float* out, 
     hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 31) / 32), dim3(256), 0, (hipStream_t)stream, ws, nch, cols, out);
     return bdetr_launch_status("colsum");
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Placement of the side stream (round 5).  HIP hands a new stream one of a few hardware queues in creation order, and which queue a
+// stream sits on relative to the caller's stream decides how well the two overlap: measured on MI355X / ROCm 7.2 with the training step
+// (tools/dp_gc_probe.py, BDETR_SIDE_QUEUE_SKIP = 0..3) the SAME step takes 25.1 / 25.3 / 25.2 / 44.3 ms on the four queues a
+// low-priority stream can land on - on the worst one every small kernel of the critical path waits for the dispatch of the side stream's
+// large grids (3-8 x their duration) - and which of the four a process gets depends on what else created streams before (creating
+// the RCCL process group before or after the model moved the step from 25.7 to 45 ms).  So the stream is CHOSEN by measurement: `ncand`
+// low-priority streams are created, each is loaded with `loads` launches of a streaming kernel over a 64-MB buffer while `ticks`
+// one-workgroup kernels run back to back on the caller's stream, and the time those take under each candidate comes back in scores_ms
+// (the second pass of two; 0.76 against 4.5 ms on the bad queue).  All candidates are returned and stay alive (idle streams cost
+// nothing; the host keeps the best and, under data parallelism, settles between the good ones by timing steps: training.Model).
+// Synchronises the streams involved: call it outside any capture.
+namespace {
+__global__ __launch_bounds__(256) void sidecal_load_kernel(f32x4* __restrict__ x, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) { f32x4 v = x[i]; v = v * 1.0001f + 1.f; x[i] = v; }
+}
+__global__ void sidecal_tick_kernel(int* p) { if (threadIdx.x == 0) p[0] += 1; }
+}  // namespace
+
+extern "C" int bdetr_side_stream_candidates(void* main_stream, int ncand, int loads, int ticks, void** streams_out, float* scores_ms) {
+    BDETR_CHECK_ARG(streams_out != nullptr && scores_ms != nullptr && ncand >= 1 && ncand <= 8 && loads >= 1 && ticks >= 1,
+                    "bdetr_side_stream_candidates: bad arguments (1 <= ncand <= 8)");
+    hipStream_t cand[8] = {};
+    for (int c = 0; c < ncand; ++c) {
+        const int rc = bdetr_low_priority_stream_create((void**)&cand[c]);
+        if (rc != 0) { for (int d = 0; d < c; ++d) (void)hipStreamDestroy(cand[d]); return rc; }
+    }
+    const int64_t n4 = (int64_t)4 << 20;                       // 64 MB
+    f32x4* buf = nullptr; int* cnt = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipStream_t ms = (hipStream_t)main_stream;
+    hipError_t e = hipMalloc((void**)&buf, n4 * sizeof(f32x4));
+    if (e == hipSuccess) e = hipMalloc((void**)&cnt, sizeof(int));
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = hipMemsetAsync(cnt, 0, sizeof(int), ms);
+    if (e == hipSuccess) e = hipMemsetAsync(buf, 0, n4 * sizeof(f32x4), ms);
+    if (e == hipSuccess) e = hipStreamSynchronize(ms);
+    for (int c = 0; c < ncand && e == hipSuccess; ++c) {
+        float ms_c = 0.f;
+        for (int pass = 0; pass < 2 && e == hipSuccess; ++pass) {
+            for (int l = 0; l < loads; ++l) hipLaunchKernelGGL(sidecal_load_kernel, dim3((unsigned)(n4 / 256)), dim3(256), 0, cand[c], buf, n4);
+            e = hipEventRecord(e0, ms);
+            for (int t = 0; t < ticks; ++t) hipLaunchKernelGGL(sidecal_tick_kernel, dim3(1), dim3(64), 0, ms, cnt);
+            if (e == hipSuccess) e = hipEventRecord(e1, ms);
+            if (e == hipSuccess) e = hipEventSynchronize(e1);
+            if (e == hipSuccess) e = hipStreamSynchronize(cand[c]);
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms_c, e0, e1);
+        }
+        scores_ms[c] = ms_c;
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (buf) (void)hipFree(buf);
+    if (cnt) (void)hipFree(cnt);
+    if (e != hipSuccess) {
+        for (int c = 0; c < ncand; ++c) (void)hipStreamDestroy(cand[c]);
+        bdetr_set_error("bdetr_side_stream_candidates: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    for (int c = 0; c < ncand; ++c) streams_out[c] = (void*)cand[c];
+    return bdetr_launch_status("side_stream_candidates");
+}

@@ -297,12 +297,49 @@ def side_stream() -> Optional["torch.cuda.Stream"]:
         if _os.environ.get("BDETR_SIDE_PRIORITY", "low") == "low":
             import ctypes as _C
             from . import _lib
-            h = _C.c_void_p()
-            _lib.check(_lib.lib().bdetr_low_priority_stream_create(_C.byref(h)), "low_priority_stream_create")
-            _SIDE["stream"] = torch.cuda.ExternalStream(h.value, device=device())
+            for _ in range(int(_os.environ.get("BDETR_SIDE_QUEUE_SKIP", "0"))):      # (probe: shift the stream onto the next hardware queue)
+                d = _C.c_void_p()
+                _lib.check(_lib.lib().bdetr_low_priority_stream_create(_C.byref(d)), "low_priority_stream_create")
+                _SIDE.setdefault("dummies", []).append(d)
+            ncand = int(_os.environ.get("BDETR_SIDE_CANDIDATES", "4"))
+            if ncand > 1 and not torch.cuda.is_current_stream_capturing():
+                # Which hardware queue the stream lands on relative to the critical path's decides how the two overlap (the same step at
+                # 25.1 / 25.3 / 25.2 / 44.3 ms on the four a low-priority stream can get, and what else created streams earlier - an RCCL
+                # process group, say - shifts which one is next): create four, measure each against the current stream
+                # (csrc/elementwise.hip bdetr_side_stream_candidates; ~20 ms, once per process), run on the best.  The others stay: a
+                # data-parallel model settles between the good ones by timing steps (training.Model._tune_side_stream).
+                hs, scores = (_C.c_void_p * ncand)(), (_C.c_float * ncand)()
+                _lib.check(_lib.lib().bdetr_side_stream_candidates(_C.c_void_p(torch.cuda.current_stream().cuda_stream), ncand, 120, 200, hs, scores),
+                           "side_stream_candidates")
+                ticks = [float(x) for x in scores]
+                best = min(range(ncand), key=lambda c: ticks[c])
+                _SIDE["candidates"] = [torch.cuda.ExternalStream(hs[c], device=device()) for c in range(ncand)]
+                _SIDE["placement"] = {"picked": best, "tick_ms": [round(x, 3) for x in ticks],
+                                      "good": [c for c in range(ncand) if ticks[c] <= 1.5 * ticks[best]]}
+                _SIDE["stream"] = _SIDE["candidates"][best]
+            else:
+                h = _C.c_void_p()
+                _lib.check(_lib.lib().bdetr_low_priority_stream_create(_C.byref(h)), "low_priority_stream_create")
+                _SIDE["stream"] = torch.cuda.ExternalStream(h.value, device=device())
         else:
             _SIDE["stream"] = torch.cuda.Stream(device=device())
     return _SIDE["stream"]
+
+
+def side_stream_placement() -> Optional[dict]:
+    """What side_stream()'s placement measurement saw: {"picked": index, "tick_ms": [per candidate], "good": [indices within 1.5 x of the
+    best]} (+ "step_ms" once a data-parallel model has timed steps on the good ones); None before the stream exists or with
+    BDETR_SIDE_CANDIDATES=1."""
+    return _SIDE.get("placement")
+
+
+def side_stream_select(index: int) -> None:
+    """Run the side work on candidate `index` from now on.  Only between steps: nothing may be pending on the current side stream (the
+    caller has joined it) and no captured step may exist that replays on it (Model drops its captures)."""
+    if _SIDE["used"]:
+        raise RuntimeError("side_stream_select: side-stream work is pending (join_side_stream first)")
+    _SIDE["stream"] = _SIDE["candidates"][index]
+    _SIDE["placement"]["picked"] = index
 
 
 def set_side_stream_enabled(on: bool) -> None:

@@ -546,6 +546,7 @@ class Model(Layer):
         self._dp = DataParallel()
         self.loss_fn.loss_scale = 1.0 / self._dp.world     # S14: per-replica loss scaled by 1/num_replicas
         self._dp_synced = False                            # variables are broadcast from rank 0 once they exist (first step)
+        self._side_tune = None                             # the side stream's placement is settled again under the collectives (_side_tune_begin)
         return self
 
     # -- one step ----------------------------------------------------------------------------
@@ -646,6 +647,8 @@ class Model(Layer):
             return None
         if self._dp is not None and (not getattr(self, "_dp_synced", True) or (self._dp.active and self._dp.overlap and self._dp._expected is None)):
             return None          # replicas not yet broadcast / the bucket table not yet calibrated (its first eager step): not now
+        if self.side_tuning_pending():
+            return None          # the side stream's placement is still being settled by timing eager steps (_side_tune_begin)
         from . import graph_replay_is_safe
         if not graph_replay_is_safe():
             if not getattr(self, "_graph_refused", False):
@@ -846,6 +849,62 @@ class Model(Layer):
                   "for the rest of this model's life; set it back to 'split' by hand if the cause was transient", file=sys.stderr)
         return logs
 
+    # -- placement of the side stream under data parallelism -------------------------------------------------------------------
+    # engine.side_stream() measures its candidates against the critical path's stream and keeps the best; that settles the single-process
+    # case (one of the four hardware queues a low-priority stream can land on costs 80 % of the step, the other three are equal).  With
+    # collectives in flight two more of the four become 10 % slower (measured over a one-rank RCCL communicator: 24.9 / 28.0 / 28.0 ms on the
+    # three "good" queues - presumably the ones that share a dispatch pipe with the communication stream and with RCCL's own stream, whose
+    # barrier packets wait for the side stream's events), and which ones cannot be seen before the collectives run.  So a data-parallel model
+    # times its first eager steps on each good candidate (SIDE_TUNE_STEPS per slot, the first of a slot discarded, GPU time of the whole
+    # step between two events on the step's stream) and keeps the fastest.  The schedule has a FIXED length - SIDE_TUNE_SLOTS slots from
+    # step SIDE_TUNE_FROM on, whatever the number of good candidates (they are cycled) - so that every rank leaves it at the same step.
+    SIDE_TUNE_FROM, SIDE_TUNE_SLOTS, SIDE_TUNE_STEPS = 3, 4, 3
+
+    def side_tuning_pending(self) -> bool:
+        return (self._dp is not None and self._dp.active and getattr(self, "_side_tune", None) != "done"
+                and os.environ.get("BDETR_SIDE_TUNE", "1") != "0")
+
+    def _side_tune_begin(self):
+        if not self.side_tuning_pending() or self.steps_done < self.SIDE_TUNE_FROM:
+            return None
+        from . import engine as _engine
+        pl = _engine.side_stream_placement()
+        st = getattr(self, "_side_tune", None)
+        if st is None:
+            good = list(pl["good"]) if pl is not None else []
+            st = self._side_tune = {"good": good, "k": 0, "ms": {c: [] for c in good}}
+        slot, rep = divmod(st["k"], self.SIDE_TUNE_STEPS)
+        if slot >= self.SIDE_TUNE_SLOTS:
+            return None
+        if len(st["good"]) < 2:
+            return ("idle", None, None)               # nothing to choose from: the schedule still runs its length (rank-independent)
+        c = st["good"][slot % len(st["good"])]
+        if rep == 0:
+            _engine.side_stream_select(c)
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        return (c, rep, ev0)
+
+    def _side_tune_end(self, tok) -> None:
+        if tok is None:
+            return
+        from . import engine as _engine
+        st = self._side_tune
+        c, rep, ev0 = tok
+        if c != "idle":
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev1.record()
+            ev1.synchronize()
+            if rep > 0:
+                st["ms"][c].append(ev0.elapsed_time(ev1))
+        st["k"] += 1
+        if st["k"] >= self.SIDE_TUNE_SLOTS * self.SIDE_TUNE_STEPS:
+            if c != "idle":
+                best = min((c for c in st["good"] if st["ms"][c]), key=lambda c: min(st["ms"][c]))
+                _engine.side_stream_select(best)
+                _engine.side_stream_placement()["step_ms"] = {c: round(min(v), 3) for c, v in st["ms"].items() if v}
+            self._side_tune = "done"
+
     def _train_step_once(self, data: dict) -> Dict[str, torch.Tensor]:
         if self.optimizer is None:
             raise RuntimeError("call compile(optimizer=...) before fit/train_step")
@@ -854,6 +913,12 @@ class Model(Layer):
             logs = self._graph_step(data, sig)
             if logs is not None:
                 return logs
+        tune = self._side_tune_begin()
+        logs = self._eager_step(data)
+        self._side_tune_end(tune)
+        return logs
+
+    def _eager_step(self, data: dict) -> Dict[str, torch.Tensor]:
         if self._dp is not None and not getattr(self, "_dp_synced", True) and self.built_variables():
             self._dp.broadcast_variables(self.variables)
             self._dp_synced = True

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define BDETR_ABI_VERSION 7
+#define BDETR_ABI_VERSION 8
 
 int         bdetr_abi_version(void);
 const char* bdetr_last_error(void);
@@ -37,6 +37,13 @@ int         bdetr_device_cus(void);
  * device's priority range (numerically larger = lower priority). */
 int         bdetr_low_priority_stream_create(void** stream_out);
 int         bdetr_stream_priority_range(int* least, int* greatest);
+/* (ABI 8) Candidates for a PLACED side stream: HIP binds a new stream to one of a few hardware queues in creation order, and the queue it
+ * shares - or does not share - a dispatch pipe with decides how two streams overlap (measured: the same training step at 25.1 / 25.3 / 25.2 /
+ * 44.3 ms on the four queues a low-priority stream can land on; engine.side_stream).  Creates `ncand` (1..8) lowest-priority non-blocking
+ * streams (-> streams_out[ncand], process lifetime) and measures for each how long `ticks` one-workgroup kernels take back to back on
+ * `main_stream` while the candidate runs `loads` launches of a streaming kernel over a 64-MB scratch buffer (-> scores_ms[ncand]; smaller
+ * = the two streams get in each other's way less).  Allocates and frees its scratch; synchronises the streams - not inside a capture. */
+int         bdetr_side_stream_candidates(void* main_stream, int ncand, int loads, int ticks, void** streams_out, float* scores_ms);
 
 /* Arithmetic of the conv/GEMM family (inputs and outputs are always fp32):
  *  BDETR_GEMM_FP32    every product on v_mfma_f32_32x32x2_f32 (exact fp32 products);

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     assert len(syms) >= 40
     assert sorted(_lib.SIGNATURES) == syms, set(syms) ^ set(_lib.SIGNATURES)
     h = _lib.lib()           # binds every symbol or raises
-    assert h.bdetr_abi_version() == 7
+    assert h.bdetr_abi_version() == 8
     for s in syms:
         assert hasattr(h, s)
 

@@ -260,6 +260,11 @@ def test_bench_multi_rank_code_path_over_one_rank_rccl(cuda, launch):
     ar = line["allreduce"]
     assert ar and ar["buckets_per_step"] >= 3 and 120e6 < ar["bytes_per_step"] < 130e6 and ar["allreduce_ms_per_step"] > 0, ar       # 31.0 M fp32 gradients
     assert line["range_guard"]["overflow_flag_after_run"] == 0 and line["range_guard"]["range_redos_in_timed_region"] == 0
+    # the weight-gradient stream was PLACED: four candidate hardware queues measured against the critical path's stream, then the good ones
+    # settled by timed data-parallel steps during set-up (engine.side_stream, training.Model._side_tune_begin)
+    pl = line["config"]["side_stream_placement"]
+    assert len(pl["tick_ms"]) == 4 and pl["picked"] in pl["good"] and pl["tick_ms"][pl["picked"]] <= 1.5 * min(pl["tick_ms"]), pl
+    assert len(pl["good"]) < 2 or (pl["step_ms"] and pl["step_ms"][str(pl["picked"])] == min(pl["step_ms"].values())), pl
     assert line["value"] > 100 and line["config"]["step_launch"] == ("hipGraph replay (segmented)" if launch == "graph" else "eager"), line["config"]["step_launch"]
     print(launch, {k: ar[k] for k in ("allreduce_ms_per_step", "algbw_GBps", "buckets_per_step")}, "images/s", line["value"])
 
@@ -335,7 +340,7 @@ def test_data_parallel_step_replays_as_hipgraphs_over_a_one_rank_rccl_communicat
     script = tmp_path / "rccl_graph.py"
     script.write_text(_WORKER_RCCL_GRAPH)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port(), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", BDETR_DP_FORCE="1",
-               HSA_ENABLE_IPC_MODE_LEGACY="0")
+               HSA_ENABLE_IPC_MODE_LEGACY="0", BDETR_SIDE_TUNE="0")       # (no placement-tuning steps: the third step must be the captured one)
     p = subprocess.run([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert p.returncode == 0 and "RCCL_GRAPH_DP_OK" in p.stdout, p.stdout[-3000:]
     print(p.stdout.strip().splitlines()[-1])
