@@ -312,7 +312,9 @@ def side_stream() -> Optional["torch.cuda.Stream"]:
                 _lib.check(_lib.lib().bdetr_side_stream_candidates(_C.c_void_p(torch.cuda.current_stream().cuda_stream), ncand, 120, 200, hs, scores),
                            "side_stream_candidates")
                 ticks = [float(x) for x in scores]
-                best = min(range(ncand), key=lambda c: ticks[c])
+                # (the FIRST candidate within 10 % of the shortest time: the good queues measure the same - 0.75 against 4.6 ms on the bad one -
+                # and creation order must not be reshuffled by measurement noise)
+                best = next(c for c in range(ncand) if ticks[c] <= 1.1 * min(ticks))
                 _SIDE["candidates"] = [torch.cuda.ExternalStream(hs[c], device=device()) for c in range(ncand)]
                 _SIDE["placement"] = {"picked": best, "tick_ms": [round(x, 3) for x in ticks],
                                       "good": [c for c in range(ncand) if ticks[c] <= 1.5 * ticks[best]]}
