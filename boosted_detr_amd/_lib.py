@@ -76,7 +76,8 @@ SIGNATURES = {
     "bdetr_last_error": (C.c_char_p, []),
     "bdetr_device_cus": (I, []),
     "bdetr_low_priority_stream_create": (I, [P]),
-    "bdetr_side_stream_candidates": (I, [P, I, I, I, P, P]),
+    "bdetr_side_stream_candidates": (I, [P, I, I, I, P, P, P]),
+    "bdetr_stream_destroy": (I, [P]),
     "bdetr_stream_priority_range": (I, [P, P]),
     "bdetr_set_gemm_precision": (I, [I]),
     "bdetr_get_gemm_precision": (I, []),

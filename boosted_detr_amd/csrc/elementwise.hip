@@ -417,8 +417,9 @@ extern "C" int bdetr_colsum(const float* x, int64_t rows, int cols, float* out, 
 // the RCCL process group before or after the model moved the step from 25.7 to 45 ms).  So the stream is CHOSEN by measurement: `ncand`
 // low-priority streams are created, each is loaded with `loads` launches of a streaming kernel over a 64-MB buffer while `ticks`
 // one-workgroup kernels run back to back on the caller's stream, and the time those take under each candidate comes back in scores_ms
-// (the second pass of two; 0.76 against 4.5 ms on the bad queue).  All candidates are returned and stay alive (idle streams cost
-// nothing; the host keeps the best and, under data parallelism, settles between the good ones by timing steps: training.Model).
+// (the second pass of two; 0.76 against 4.5 ms on the bad queue; unloaded_ms = the same ticks with nothing beside them).  The candidates
+// are returned; the host keeps the first good one and destroys the others (bdetr_stream_destroy: three more idle low-priority queues
+// measured 0.5 % on the step), a data-parallel model asks for more and settles between the good ones by timing steps (training.Model).
 // Synchronises the streams involved: call it outside any capture.
 namespace {
 __global__ __launch_bounds__(256) void sidecal_load_kernel(f32x4* __restrict__ x, int64_t n4) {
@@ -428,7 +429,14 @@ __global__ __launch_bounds__(256) void sidecal_load_kernel(f32x4* __restrict__ x
 __global__ void sidecal_tick_kernel(int* p) { if (threadIdx.x == 0) p[0] += 1; }
 }  // namespace
 
-extern "C" int bdetr_side_stream_candidates(void* main_stream, int ncand, int loads, int ticks, void** streams_out, float* scores_ms) {
+extern "C" int bdetr_stream_destroy(void* stream) {
+    BDETR_CHECK_ARG(stream != nullptr, "bdetr_stream_destroy: null stream");
+    const hipError_t e = hipStreamDestroy((hipStream_t)stream);
+    if (e != hipSuccess) { bdetr_set_error("bdetr_stream_destroy: %s", hipGetErrorString(e)); return (int)e; }
+    return 0;
+}
+
+extern "C" int bdetr_side_stream_candidates(void* main_stream, int ncand, int loads, int ticks, void** streams_out, float* scores_ms, float* unloaded_ms) {
     BDETR_CHECK_ARG(streams_out != nullptr && scores_ms != nullptr && ncand >= 1 && ncand <= 8 && loads >= 1 && ticks >= 1,
                     "bdetr_side_stream_candidates: bad arguments (1 <= ncand <= 8)");
     hipStream_t cand[8] = {};
@@ -446,6 +454,17 @@ extern "C" int bdetr_side_stream_candidates(void* main_stream, int ncand, int lo
     if (e == hipSuccess) e = hipMemsetAsync(cnt, 0, sizeof(int), ms);
     if (e == hipSuccess) e = hipMemsetAsync(buf, 0, n4 * sizeof(f32x4), ms);
     if (e == hipSuccess) e = hipStreamSynchronize(ms);
+    if (unloaded_ms != nullptr) {                               // the reference: the same ticks with nothing beside them
+        float ms_0 = 0.f;
+        for (int pass = 0; pass < 2 && e == hipSuccess; ++pass) {
+            e = hipEventRecord(e0, ms);
+            for (int t = 0; t < ticks; ++t) hipLaunchKernelGGL(sidecal_tick_kernel, dim3(1), dim3(64), 0, ms, cnt);
+            if (e == hipSuccess) e = hipEventRecord(e1, ms);
+            if (e == hipSuccess) e = hipEventSynchronize(e1);
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms_0, e0, e1);
+        }
+        *unloaded_ms = ms_0;
+    }
     for (int c = 0; c < ncand && e == hipSuccess; ++c) {
         float ms_c = 0.f;
         for (int pass = 0; pass < 2 && e == hipSuccess; ++pass) {

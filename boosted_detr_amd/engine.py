@@ -305,20 +305,20 @@ def side_stream() -> Optional["torch.cuda.Stream"]:
             if ncand > 1 and not torch.cuda.is_current_stream_capturing():
                 # Which hardware queue the stream lands on relative to the critical path's decides how the two overlap (the same step at
                 # 25.1 / 25.3 / 25.2 / 44.3 ms on the four a low-priority stream can get, and what else created streams earlier - an RCCL
-                # process group, say - shifts which one is next): create four, measure each against the current stream
-                # (csrc/elementwise.hip bdetr_side_stream_candidates; ~20 ms, once per process), run on the best.  The others stay: a
-                # data-parallel model settles between the good ones by timing steps (training.Model._tune_side_stream).
-                hs, scores = (_C.c_void_p * ncand)(), (_C.c_float * ncand)()
-                _lib.check(_lib.lib().bdetr_side_stream_candidates(_C.c_void_p(torch.cuda.current_stream().cuda_stream), ncand, 120, 200, hs, scores),
-                           "side_stream_candidates")
-                ticks = [float(x) for x in scores]
-                # (the FIRST candidate within 10 % of the shortest time: the good queues measure the same - 0.75 against 4.6 ms on the bad one -
-                # and creation order must not be reshuffled by measurement noise)
-                best = next(c for c in range(ncand) if ticks[c] <= 1.1 * min(ticks))
-                _SIDE["candidates"] = [torch.cuda.ExternalStream(hs[c], device=device()) for c in range(ncand)]
-                _SIDE["placement"] = {"picked": best, "tick_ms": [round(x, 3) for x in ticks],
-                                      "good": [c for c in range(ncand) if ticks[c] <= 1.5 * ticks[best]]}
-                _SIDE["stream"] = _SIDE["candidates"][best]
+                # process group, say - shifts which one is next).  So a new stream is MEASURED against the current stream
+                # (csrc/elementwise.hip bdetr_side_stream_candidates: the critical path's small kernels under the candidate's load, 0.75 ms
+                # on a good queue against 4.6 on the bad one and 0.5 with no load) and only kept when it is good; a bad one is
+                # followed by the next candidate, up to `ncand`.  ~5 ms per candidate, once per process.
+                _SIDE["placement"] = {"picked": None, "tick_ms": [], "unloaded_ms": None, "good": [], "limit": ncand}
+                _SIDE["candidates"] = []
+                _more_candidates(1)
+                while not _SIDE["placement"]["good"] and len(_SIDE["placement"]["tick_ms"]) < ncand:
+                    _more_candidates(1)
+                pl = _SIDE["placement"]
+                pick = pl["good"][0] if pl["good"] else min(range(len(pl["tick_ms"])), key=lambda c: pl["tick_ms"][c])
+                pl["picked"] = pick
+                _SIDE["stream"] = _SIDE["candidates"][pick]
+                side_stream_release()
             else:
                 h = _C.c_void_p()
                 _lib.check(_lib.lib().bdetr_low_priority_stream_create(_C.byref(h)), "low_priority_stream_create")
@@ -328,9 +328,52 @@ def side_stream() -> Optional["torch.cuda.Stream"]:
     return _SIDE["stream"]
 
 
+SIDE_BAD_RATIO = 3.0        # a candidate is good when the critical path's ticks under its load take < 3 x their unloaded time (measured: 1.5 x / 9 x)
+
+
+def _more_candidates(n: int) -> None:
+    """Create and measure `n` more low-priority candidates against the current stream (not inside a capture)."""
+    import ctypes as _C
+    from . import _lib
+    pl = _SIDE["placement"]
+    hs, scores, base = (_C.c_void_p * n)(), (_C.c_float * n)(), _C.c_float(0.0)
+    _lib.check(_lib.lib().bdetr_side_stream_candidates(_C.c_void_p(torch.cuda.current_stream().cuda_stream), n, 120, 200, hs, scores, _C.byref(base)),
+               "side_stream_candidates")
+    if pl["unloaded_ms"] is None:
+        pl["unloaded_ms"] = round(float(base.value), 3)
+    for c in range(n):
+        _SIDE["candidates"].append(torch.cuda.ExternalStream(hs[c], device=device()))
+        pl["tick_ms"].append(round(float(scores[c]), 3))
+        if float(scores[c]) < SIDE_BAD_RATIO * max(pl["unloaded_ms"], 1e-3):
+            pl["good"].append(len(pl["tick_ms"]) - 1)
+
+
+def side_stream_expand() -> list:
+    """Measure candidates up to the limit (BDETR_SIDE_CANDIDATES, 4) and return the indices of the good ones - for a caller that wants to
+    choose between them by timing real steps (training.Model under data parallelism).  Between steps, not inside a capture."""
+    pl = _SIDE.get("placement")
+    if pl is None or _SIDE["used"] or torch.cuda.is_current_stream_capturing():
+        return [] if pl is None else [c for c in pl["good"] if _SIDE["candidates"][c] is not None]
+    while len(pl["tick_ms"]) < pl["limit"]:
+        _more_candidates(1)
+    return [c for c in pl["good"] if _SIDE["candidates"][c] is not None]
+
+
+def side_stream_release() -> None:
+    """Destroy every candidate but the one in use (idle low-priority queues are not free: three of them measured 0.5 % on the step)."""
+    from . import _lib
+    if _SIDE["used"]:
+        raise RuntimeError("side_stream_release: side-stream work is pending (join_side_stream first)")
+    for c, st in enumerate(_SIDE.get("candidates", [])):
+        if st is not None and st is not _SIDE["stream"]:
+            st.synchronize()
+            _lib.check(_lib.lib().bdetr_stream_destroy(st.cuda_stream), "stream_destroy")
+            _SIDE["candidates"][c] = None
+
+
 def side_stream_placement() -> Optional[dict]:
-    """What side_stream()'s placement measurement saw: {"picked": index, "tick_ms": [per candidate], "good": [indices within 1.5 x of the
-    best]} (+ "step_ms" once a data-parallel model has timed steps on the good ones); None before the stream exists or with
+    """What side_stream()'s placement measurement saw: {"picked": index, "tick_ms": [per candidate measured so far], "unloaded_ms", "good":
+    [indices]} (+ "step_ms" once a data-parallel model has timed steps on the good ones); None before the stream exists or with
     BDETR_SIDE_CANDIDATES=1."""
     return _SIDE.get("placement")
 
@@ -340,6 +383,8 @@ def side_stream_select(index: int) -> None:
     caller has joined it) and no captured step may exist that replays on it (Model drops its captures)."""
     if _SIDE["used"]:
         raise RuntimeError("side_stream_select: side-stream work is pending (join_side_stream first)")
+    if _SIDE["candidates"][index] is None:
+        raise RuntimeError(f"side_stream_select: candidate {index} was released")
     _SIDE["stream"] = _SIDE["candidates"][index]
     _SIDE["placement"]["picked"] = index
 

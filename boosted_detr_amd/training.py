@@ -850,8 +850,8 @@ class Model(Layer):
         return logs
 
     # -- placement of the side stream under data parallelism -------------------------------------------------------------------
-    # engine.side_stream() measures its candidates against the critical path's stream and keeps the best; that settles the single-process
-    # case (one of the four hardware queues a low-priority stream can land on costs 80 % of the step, the other three are equal).  With
+    # engine.side_stream() measures its candidates against the critical path's stream and keeps the first good one; that settles the
+    # single-process case (one of the four hardware queues a low-priority stream can land on costs 80 % of the step, the other three are equal).  With
     # collectives in flight two more of the four become 10 % slower (measured over a one-rank RCCL communicator: 24.9 / 28.0 / 28.0 ms on the
     # three "good" queues - presumably the ones that share a dispatch pipe with the communication stream and with RCCL's own stream, whose
     # barrier packets wait for the side stream's events), and which ones cannot be seen before the collectives run.  So a data-parallel model
@@ -868,10 +868,9 @@ class Model(Layer):
         if not self.side_tuning_pending() or self.steps_done < self.SIDE_TUNE_FROM:
             return None
         from . import engine as _engine
-        pl = _engine.side_stream_placement()
         st = getattr(self, "_side_tune", None)
         if st is None:
-            good = list(pl["good"]) if pl is not None else []
+            good = _engine.side_stream_expand() if _engine.side_stream_placement() is not None else []      # measures the remaining candidates
             st = self._side_tune = {"good": good, "k": 0, "ms": {c: [] for c in good}}
         slot, rep = divmod(st["k"], self.SIDE_TUNE_STEPS)
         if slot >= self.SIDE_TUNE_SLOTS:
@@ -903,6 +902,8 @@ class Model(Layer):
                 best = min((c for c in st["good"] if st["ms"][c]), key=lambda c: min(st["ms"][c]))
                 _engine.side_stream_select(best)
                 _engine.side_stream_placement()["step_ms"] = {c: round(min(v), 3) for c, v in st["ms"].items() if v}
+            if _engine.side_stream_placement() is not None:
+                _engine.side_stream_release()              # the candidates not chosen are destroyed (idle queues are not free)
             self._side_tune = "done"
 
     def _train_step_once(self, data: dict) -> Dict[str, torch.Tensor]:

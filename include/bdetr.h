@@ -42,8 +42,10 @@ int         bdetr_stream_priority_range(int* least, int* greatest);
  * 44.3 ms on the four queues a low-priority stream can land on; engine.side_stream).  Creates `ncand` (1..8) lowest-priority non-blocking
  * streams (-> streams_out[ncand], process lifetime) and measures for each how long `ticks` one-workgroup kernels take back to back on
  * `main_stream` while the candidate runs `loads` launches of a streaming kernel over a 64-MB scratch buffer (-> scores_ms[ncand]; smaller
- * = the two streams get in each other's way less).  Allocates and frees its scratch; synchronises the streams - not inside a capture. */
-int         bdetr_side_stream_candidates(void* main_stream, int ncand, int loads, int ticks, void** streams_out, float* scores_ms);
+ * = the two streams get in each other's way less; unloaded_ms, may be null: the same ticks with no load beside them).  Allocates and
+ * frees its scratch; synchronises the streams - not inside a capture.  bdetr_stream_destroy: for the candidates not kept. */
+int         bdetr_side_stream_candidates(void* main_stream, int ncand, int loads, int ticks, void** streams_out, float* scores_ms, float* unloaded_ms);
+int         bdetr_stream_destroy(void* stream);
 
 /* Arithmetic of the conv/GEMM family (inputs and outputs are always fp32):
  *  BDETR_GEMM_FP32    every product on v_mfma_f32_32x32x2_f32 (exact fp32 products);

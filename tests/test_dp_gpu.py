@@ -263,7 +263,7 @@ def test_bench_multi_rank_code_path_over_one_rank_rccl(cuda, launch):
     # the weight-gradient stream was PLACED: four candidate hardware queues measured against the critical path's stream, then the good ones
     # settled by timed data-parallel steps during set-up (engine.side_stream, training.Model._side_tune_begin)
     pl = line["config"]["side_stream_placement"]
-    assert len(pl["tick_ms"]) == 4 and pl["picked"] in pl["good"] and pl["tick_ms"][pl["picked"]] <= 1.5 * min(pl["tick_ms"]), pl
+    assert len(pl["tick_ms"]) == 4 and pl["picked"] in pl["good"] and pl["tick_ms"][pl["picked"]] < 3 * pl["unloaded_ms"], pl
     assert len(pl["good"]) < 2 or (pl["step_ms"] and pl["step_ms"][str(pl["picked"])] == min(pl["step_ms"].values())), pl
     assert line["value"] > 100 and line["config"]["step_launch"] == ("hipGraph replay (segmented)" if launch == "graph" else "eager"), line["config"]["step_launch"]
     print(launch, {k: ar[k] for k in ("allreduce_ms_per_step", "algbw_GBps", "buckets_per_step")}, "images/s", line["value"])

@@ -653,15 +653,17 @@ def test_compact_stride2_gradients_and_their_fallbacks_give_the_same_step(cuda, 
 
 
 def test_side_stream_is_placed_by_measurement(cuda):
-    """engine.side_stream(): four low-priority candidates, each measured against the critical path's stream (how long 200 one-workgroup
-    kernels take there while the candidate streams 120 passes over 64 MB); the stream in use is the one with the shortest time.  On
-    MI355X / ROCm 7.2 one of the four hardware queues costs the training step 80 % - it shows up here as a 5-6 x longer time."""
+    """engine.side_stream(): a low-priority candidate is measured against the critical path's stream (how long 200 one-workgroup kernels
+    take there while the candidate streams 120 passes over 64 MB, against the same ticks with no load) and kept only when it is good; a bad
+    one is followed by the next, up to four.  On MI355X / ROCm 7.2 one of the four hardware queues costs the training step 80 % (DESIGN
+    5c) - it shows up here as 9 x the unloaded time against 1.5 x."""
     from boosted_detr_amd import engine
     s = engine.side_stream()
     pl = engine.side_stream_placement()
     if pl is None:
         pytest.skip("side stream created without candidates (BDETR_SIDE_CANDIDATES=1 or BDETR_SIDE_PRIORITY != low)")
-    assert len(pl["tick_ms"]) == 4 and all(t > 0 for t in pl["tick_ms"]), pl
-    assert pl["picked"] in pl["good"] and pl["tick_ms"][pl["picked"]] <= 1.5 * min(pl["tick_ms"]), pl
-    assert s is engine._SIDE["candidates"][pl["picked"]]
-    print("side-stream candidates, ms of the critical path's ticks under each:", pl["tick_ms"], "picked", pl["picked"])
+    assert 1 <= len(pl["tick_ms"]) <= 4 and all(t > 0 for t in pl["tick_ms"]) and pl["unloaded_ms"] > 0, pl
+    assert pl["picked"] in pl["good"] and pl["tick_ms"][pl["picked"]] < engine.SIDE_BAD_RATIO * pl["unloaded_ms"], pl
+    assert all(t >= engine.SIDE_BAD_RATIO * pl["unloaded_ms"] for t in pl["tick_ms"][:pl["picked"]]), pl          # whatever was skipped was bad
+    assert s is engine._SIDE["candidates"][pl["picked"]] and sum(c is not None for c in engine._SIDE["candidates"]) == 1     # the others are gone
+    print("side-stream candidates, ms of the critical path's ticks under each:", pl["tick_ms"], "unloaded", pl["unloaded_ms"], "picked", pl["picked"])
