@@ -855,8 +855,9 @@ class Model(Layer):
     # collectives in flight two more of the four become 10 % slower (measured over a one-rank RCCL communicator: 24.9 / 28.0 / 28.0 ms on the
     # three "good" queues - presumably the ones that share a dispatch pipe with the communication stream and with RCCL's own stream, whose
     # barrier packets wait for the side stream's events), and which ones cannot be seen before the collectives run.  So a data-parallel model
-    # times its first eager steps on each good candidate (SIDE_TUNE_STEPS per slot, the first of a slot discarded, GPU time of the whole
-    # step between two events on the step's stream) and keeps the fastest.  The schedule has a FIXED length - SIDE_TUNE_SLOTS slots from
+    # times its first eager steps on each good candidate (SIDE_TUNE_STEPS per slot, the first of a slot discarded; GPU time between two events
+    # on the step's stream: step begin -> the join of the side stream behind the backward pass, i.e. BEFORE the step waits for its
+    # collectives - a rank times its own streams, not the slowest replica's) and keeps the fastest.  The schedule has a FIXED length - SIDE_TUNE_SLOTS slots from
     # step SIDE_TUNE_FROM on, whatever the number of good candidates (they are cycled) - so that every rank leaves it at the same step.
     SIDE_TUNE_FROM, SIDE_TUNE_SLOTS, SIDE_TUNE_STEPS = 3, 4, 3
 
@@ -876,23 +877,26 @@ class Model(Layer):
         if slot >= self.SIDE_TUNE_SLOTS:
             return None
         if len(st["good"]) < 2:
-            return ("idle", None, None)               # nothing to choose from: the schedule still runs its length (rank-independent)
+            return ("idle", None, None, [None])       # nothing to choose from: the schedule still runs its length (rank-independent)
         c = st["good"][slot % len(st["good"])]
         if rep == 0:
             _engine.side_stream_select(c)
         ev0 = torch.cuda.Event(enable_timing=True)
         ev0.record()
-        return (c, rep, ev0)
+        return (c, rep, ev0, [None])
 
     def _side_tune_end(self, tok) -> None:
         if tok is None:
             return
         from . import engine as _engine
         st = self._side_tune
-        c, rep, ev0 = tok
+        c, rep, ev0, end = tok
+        self._side_tune_tok = None
         if c != "idle":
-            ev1 = torch.cuda.Event(enable_timing=True)
-            ev1.record()
+            ev1 = end[0]
+            if ev1 is None:
+                ev1 = torch.cuda.Event(enable_timing=True)
+                ev1.record()
             ev1.synchronize()
             if rep > 0:
                 st["ms"][c].append(ev0.elapsed_time(ev1))
@@ -914,7 +918,7 @@ class Model(Layer):
             logs = self._graph_step(data, sig)
             if logs is not None:
                 return logs
-        tune = self._side_tune_begin()
+        tune = self._side_tune_tok = self._side_tune_begin()
         logs = self._eager_step(data)
         self._side_tune_end(tune)
         return logs
@@ -924,6 +928,12 @@ class Model(Layer):
             self._dp.broadcast_variables(self.variables)
             self._dp_synced = True
         self.forward_backward(data)
+        tok = getattr(self, "_side_tune_tok", None)
+        if tok is not None and tok[2] is not None:
+            # placement tuning: the timed interval ends HERE - behind the join of the side stream, before the step waits for its collectives
+            # (a rank must time its own streams, not the slowest replica's)
+            tok[3][0] = torch.cuda.Event(enable_timing=True)
+            tok[3][0].record()
         if self._dp is not None and not getattr(self, "_dp_synced", True):
             # build-by-first-call just created the variables: replicas adopt rank 0's initial values before any update
             self._dp.broadcast_variables(self.variables)
