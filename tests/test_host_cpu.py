@@ -305,3 +305,47 @@ def test_data_parallel_cuda_branch_with_fake_streams(monkeypatch):
     assert dp3._bounds[0] == (n - B, n) and dp3._bounds[-2:] == [(T, n - 3 * B), (0, T)] and len(dp3._bounds) == 5, dp3._bounds
     assert all(a[0] == b[1] for a, b in zip(dp3._bounds[:-1], dp3._bounds[1:]))            # contiguous cover, high to low
     assert dp3._var_bucket[id(vb[0])] == (4, 4) and dp3._var_bucket[id(vb[2])] == (4, 3) and dp3._var_bucket[id(vb[3])][0] == 1      # vb[2] straddles the cut: counted in both
+
+
+@pytest.mark.parametrize("good, step_ms, want", [([0, 1, 2], {0: 28.0, 1: 25.0, 2: 28.5}, 1), ([1, 3], {1: 27.0, 3: 24.9}, 3), ([2], {}, 2), ([], {}, None)])
+def test_side_stream_tuning_schedule_has_a_fixed_length_and_keeps_the_fastest_candidate(monkeypatch, good, step_ms, want):
+    """training.Model._side_tune_begin / _side_tune_end (the data-parallel model settles between the good side-stream candidates by timing its
+    first eager steps) with fakes for the engine and the events: whatever the number of good candidates, tuning ends at the SAME step - every
+    rank must leave it together: the captured step and bench.py's set-up loop key on it - the first step of a slot is not counted, the
+    fastest candidate is selected and the others released."""
+    import types
+    from boosted_detr_amd import training, engine
+    clock = [0.0]
+    sel, released = [], []
+
+    class FakeEvent:
+        def __init__(self, enable_timing=False): self.t = None
+        def record(self): self.t = clock[0]
+        def synchronize(self): pass
+        def elapsed_time(self, other): return other.t - self.t
+    monkeypatch.setattr(training.torch, "cuda", types.SimpleNamespace(Event=FakeEvent))
+    placement = {"picked": good[0], "good": list(good)} if good else None            # None: no measured side stream (BDETR_SIDE_CANDIDATES=1, side stream off)
+    monkeypatch.setattr(engine, "side_stream_placement", lambda: placement)
+    monkeypatch.setattr(engine, "side_stream_expand", lambda: list(good))
+    monkeypatch.setattr(engine, "side_stream_select", lambda c: (sel.append(c), placement.__setitem__("picked", c)))
+    monkeypatch.setattr(engine, "side_stream_release", lambda: released.append(True))
+    m = training.Model.__new__(training.Model)
+    m._dp = types.SimpleNamespace(active=True)
+    m._side_tune, m.steps_done = None, 0
+    first_done = None
+    for step in range(30):
+        pending = m.side_tuning_pending()
+        tok = m._side_tune_tok = m._side_tune_begin()
+        if tok is not None and tok[2] is not None:
+            clock[0] += step_ms[tok[0]] + (7.0 if tok[1] == 0 else 0.0)       # the first step of a slot is slower (and must not count)
+            tok[3][0] = FakeEvent(); tok[3][0].record()
+        m._side_tune_end(tok)
+        m.steps_done += 1
+        if pending and not m.side_tuning_pending() and first_done is None:
+            first_done = m.steps_done
+    assert first_done == training.Model.SIDE_TUNE_FROM + training.Model.SIDE_TUNE_SLOTS * training.Model.SIDE_TUNE_STEPS, first_done
+    if len(good) >= 2:
+        assert placement["picked"] == want and sel[-1] == want and released, (placement, sel)
+        assert placement["step_ms"] == {c: step_ms[c] for c in good}, placement
+    else:
+        assert not sel, sel
