@@ -380,7 +380,7 @@ def side_stream_placement() -> Optional[dict]:
 
 def side_stream_select(index: int) -> None:
     """Run the side work on candidate `index` from now on.  Only between steps: nothing may be pending on the current side stream (the
-    caller has joined it) and no captured step may exist that replays on it (Model drops its captures)."""
+    caller has joined it).  Captured steps are not tied to it: their side graphs replay on whatever side_stream() returns at replay time."""
     if _SIDE["used"]:
         raise RuntimeError("side_stream_select: side-stream work is pending (join_side_stream first)")
     if _SIDE["candidates"][index] is None:
