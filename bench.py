@@ -113,11 +113,22 @@ class quiet_gc:
     the collector's help only between its two halves), so nothing accumulates while it is off."""
     last_full_collection_ms = None
 
-    def __enter__(self):
+    def __init__(self, collect=True):
+        self.collect = collect
+
+    @staticmethod
+    def full_collection():
+        """The full collection of a leg, BEFORE that leg's untimed warm-up steps: it idles the GPU for tens of milliseconds, and a timed region
+        that starts right behind such a gap measured 2 ms longer (10-step regions: 25.13 against 24.91 ms/step at 40 steps, tools/run_steps_sweep.sh)."""
         import gc
         t = time.perf_counter()
         gc.collect()
         quiet_gc.last_full_collection_ms = round((time.perf_counter() - t) * 1e3, 2)
+
+    def __enter__(self):
+        import gc
+        if self.collect:
+            quiet_gc.full_collection()
         self.was = gc.isenabled()
         gc.disable()
         return self
@@ -447,7 +458,7 @@ def main():
     launch_probe = None
     if model.use_graph and model._graphs and not args.graph and os.environ.get("BDETR_LAUNCH_PROBE", "1") != "0":
         def probe(n):
-            with quiet_gc():
+            with quiet_gc(collect=False):
                 barrier()
                 tp = time.perf_counter()
                 for _ in range(n):
@@ -460,9 +471,11 @@ def main():
                 dt = float(t.item())
             return dt / n * 1e3
         P = 10
+        quiet_gc.full_collection()
         run_step(batch)
         g_ms = probe(P)
         model.use_graph = False
+        quiet_gc.full_collection()
         for _ in range(3):
             run_step(batch)
         e_ms = probe(P)
@@ -470,6 +483,8 @@ def main():
         launch_probe = {"steps_each": P, "graph_replay_ms_per_step": round(g_ms, 3), "eager_ms_per_step": round(e_ms, 3),
                         "chosen": "hipGraph replay" if model.use_graph else "eager"}
         note(f"launch probe: replay {g_ms:.2f} ms/step, eager {e_ms:.2f} ms/step -> {launch_probe['chosen']}")
+    quiet_gc.full_collection()                 # (before the warm-up steps, not between them and the timed region: see quiet_gc)
+    gc_ms = [quiet_gc.last_full_collection_ms]
     for i in range(max(args.warmup, 1)):
         tw = time.perf_counter()
         run_step(batch)
@@ -483,14 +498,13 @@ def main():
     want_roof = not args.no_roofline          # every rank runs the bracketed region (collectives must match); rank 0 records
 
     def timed_region():
-        with quiet_gc():
+        with quiet_gc(collect=False):
             barrier()
             t0 = time.perf_counter()
             for _ in range(args.steps):
                 run_step(batch)
             barrier()
             dt = time.perf_counter() - t0
-        gc_ms[0] = quiet_gc.last_full_collection_ms
         # The range guard of the timed region: resolve the flag snapshots still in flight (outside the timed region) and report.  A
         # raised guard means steps inside the region applied no update and were redone: the line says so instead of hiding it.
         model.guard_flush()
@@ -499,7 +513,6 @@ def main():
                     "overflow_flag_after_run": int(K.overflow_flag().item()), "policy_guarded": bool(model._guarded()),
                     "check": "the flag is logged to pinned memory by the last kernel of every step and examined 2 steps later (Model._guard_poll)"}
 
-    gc_ms = [None]
     elapsed, guard = timed_region()
     replayed = bool(model.use_graph and model._graphs)
     step_launch = "hipGraph replay (segmented)" if replayed else ("eager (graph replay refused: BDETR_ZERO_MEMSET=1 without "
@@ -607,10 +620,11 @@ def main():
         batch32 = {"image": to_device(host32["image"]), "category": to_device(host32["category"], torch.int32),
                    "attribute": to_device(host32["attribute"], torch.int32),
                    "bbox": to_device(host32["bbox"]), "num_objects": to_device(host32["num_objects"], torch.int32)}
+        quiet_gc.full_collection()
         for _ in range(2):
             model.train_step(batch32)
         k32 = max(3, args.steps // 2)
-        with quiet_gc():
+        with quiet_gc(collect=False):
             barrier()
             t2 = time.perf_counter()
             for _ in range(k32):
@@ -632,10 +646,11 @@ def main():
         keep = (model.train_gemm_precision, model.train_grad_precision)
         model.train_gemm_precision, model.train_grad_precision = fwd_policy, grad_policy
         try:
+            quiet_gc.full_collection()
             for _ in range(4 if model.use_graph else 2):
                 model.train_step(batch)
             kf = max(3, args.steps // 2)
-            with quiet_gc():
+            with quiet_gc(collect=False):
                 barrier()
                 t3 = time.perf_counter()
                 for _ in range(kf):
@@ -674,12 +689,13 @@ def main():
         b2 = {"image": to_device(h2["image"]), "category": to_device(h2["category"], torch.int32), "attribute": to_device(h2["attribute"], torch.int32),
               "bbox": to_device(h2["bbox"]), "num_objects": to_device(h2["num_objects"], torch.int32)}
         m2.use_graph = want_graph and graph_ok
+        quiet_gc.full_collection()
         for _ in range(5):
             m2.train_step(b2)
         m2.guard_flush()
         r2 = m2.range_redos
         k2 = max(3, args.steps // 2)
-        with quiet_gc():
+        with quiet_gc(collect=False):
             barrier()
             t4 = time.perf_counter()
             for _ in range(k2):
@@ -736,7 +752,7 @@ def main():
             "allreduce": allreduce,
             "panoptic": panoptic,
             "host_gc": {"collector_off_in_timed_regions": True, "full_collection_before_the_timed_region_ms": gc_ms[0],
-                        "note": "every timed region starts with gc.collect() and runs with the cyclic collector off (bench.py quiet_gc): a generation-2 pass of this process is tens of ms and would land inside a 5-10-step region by allocation count"},
+                        "note": "one gc.collect() before the warm-up steps of every leg, then the leg's timed region runs with the cyclic collector off (bench.py quiet_gc): a generation-2 pass of this process is tens of ms and would land inside a 5-10-step region by allocation count"},
             "value_fp32_policy": fp32_line,
             "value_fp32_grade": grade_line,
             "roofline": roof,
